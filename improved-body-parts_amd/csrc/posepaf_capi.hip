@@ -1,0 +1,349 @@
+// posepaf_capi.hip -- the C ABI of libposepaf.so (include/posepaf.h): context/workspace management, the native
+// batched entry points and the drop-in replacements of the reference's utils/pafprocess functions.
+// Everything numeric happens in the HIP kernels (posepaf_kernels.hip); the host code only validates arguments,
+// groups the caller's peak rows by part (the reference's own bucketing loop, pafprocess.cpp:29-41, which is
+// index bookkeeping) and moves bytes.  There is no CPU implementation to fall back to.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "posepaf_internal.h"
+
+struct pp_ctx {
+    int device = 0;
+    int max_batch = 0, max_h = 0, max_w = 0, maxp = 0, cap = 0;
+    int hip_err = 0;
+    // device workspace
+    float4 *d_peaks = nullptr;    // [max_batch][18][maxp] (x, y, score, id bits)
+    int *d_counts = nullptr;      // [max_batch][18]
+    float4 *d_conns = nullptr;    // [max_batch][30][maxp] (cid1 bits, cid2 bits, score, length)
+    int *d_conn_counts = nullptr; // [max_batch][30]
+    unsigned *d_status = nullptr; // [max_batch]
+    pp_record *d_records = nullptr;  // [max_batch] (used when the caller passes NULL, and by the drop-in path)
+    float *d_paf = nullptr;       // drop-in path: the caller's up-sampled (H,W,C) map
+    size_t d_paf_bytes = 0;
+    hipStream_t last_stream = nullptr;
+    int last_batch = 0;
+    const float4 *last_peaks = nullptr;
+    const int *last_counts = nullptr;
+    // drop-in path results (host)
+    pp_record h_record;
+    std::vector<int> line_x, line_y;
+    std::vector<float> line_s;
+    bool have_result = false;
+};
+
+namespace {
+
+int fail_hip(pp_ctx *c, hipError_t e) {
+    if (c) c->hip_err = (int)e;
+    return PP_ERR_HIP;
+}
+
+#define PP_HIP(ctx, call)                               \
+    do {                                                \
+        hipError_t e__ = (call);                        \
+        if (e__ != hipSuccess) return fail_hip(ctx, e__); \
+    } while (0)
+
+void free_ctx(pp_ctx *c) {
+    if (!c) return;
+    (void)hipFree(c->d_peaks);
+    (void)hipFree(c->d_counts);
+    (void)hipFree(c->d_conns);
+    (void)hipFree(c->d_conn_counts);
+    (void)hipFree(c->d_status);
+    (void)hipFree(c->d_records);
+    (void)hipFree(c->d_paf);
+    delete c;
+}
+
+int check_shape(const pp_ctx *c, int batch, int dtype, int h, int w) {
+    if (!c || batch <= 0 || h <= 0 || w <= 0 || (dtype != PP_F16 && dtype != PP_F32)) return PP_ERR_BAD_ARG;
+    if (batch > c->max_batch || (size_t)h * w > (size_t)c->max_h * c->max_w) return PP_ERR_TOO_LARGE;
+    const int elem = dtype == PP_F16 ? 2 : 4;
+    if (pp::lds_bytes_heat(elem, h, w, c->maxp) > pp::kMaxDynLds) return PP_ERR_TOO_LARGE;
+    if (pp::lds_bytes_limb(elem, h, w, c->maxp, c->cap) > pp::kMaxDynLds) return PP_ERR_TOO_LARGE;
+    return PP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pp_device_available(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n > 0 ? 1 : 0;
+}
+
+const char *pp_status_string(int status) {
+    switch (status) {
+        case PP_OK: return "ok";
+        case PP_ERR_NO_DEVICE: return "no HIP device (this library has no CPU path)";
+        case PP_ERR_BAD_ARG: return "bad argument";
+        case PP_ERR_TOO_LARGE: return "batch or map size beyond the context's capacity / LDS";
+        case PP_ERR_HIP: return "HIP runtime error (see pp_last_hip_error)";
+        case PP_ERR_OVERFLOW: return "capacity exceeded (peaks per part or humans)";
+        default: return "unknown status";
+    }
+}
+
+int pp_create(pp_ctx **out, int device, int max_batch, int max_h, int max_w, int max_peaks_per_part) {
+    if (!out || max_batch <= 0 || max_h <= 0 || max_w <= 0 || max_peaks_per_part <= 0 ||
+        max_peaks_per_part > PP_MAX_PEAKS_PER_PART_LIMIT)
+        return PP_ERR_BAD_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return PP_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return PP_ERR_NO_DEVICE;
+    pp_ctx *c = new pp_ctx();
+    c->device = device;
+    c->max_batch = max_batch;
+    c->max_h = max_h;
+    c->max_w = max_w;
+    c->maxp = max_peaks_per_part;
+    c->cap = max_peaks_per_part * max_peaks_per_part < 1024 ? max_peaks_per_part * max_peaks_per_part : 1024;
+    hipError_t e = pp::init_kernel_attributes();
+    const size_t B = (size_t)max_batch;
+    if (e == hipSuccess) e = hipMalloc(&c->d_peaks, B * PP_NUM_PART * c->maxp * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc(&c->d_counts, B * PP_NUM_PART * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&c->d_conns, B * PP_NUM_LIMB * c->maxp * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc(&c->d_conn_counts, B * PP_NUM_LIMB * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&c->d_status, B * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc(&c->d_records, B * sizeof(pp_record));
+    if (e == hipSuccess) e = hipMemset(c->d_counts, 0, B * PP_NUM_PART * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(c->d_conn_counts, 0, B * PP_NUM_LIMB * sizeof(int));
+    if (e != hipSuccess) {
+        free_ctx(c);
+        return PP_ERR_HIP;
+    }
+    *out = c;
+    return PP_OK;
+}
+
+int pp_destroy(pp_ctx *ctx) {
+    if (!ctx) return PP_ERR_BAD_ARG;
+    (void)hipSetDevice(ctx->device);
+    free_ctx(ctx);
+    return PP_OK;
+}
+
+int pp_last_hip_error(const pp_ctx *ctx) { return ctx ? ctx->hip_err : 0; }
+
+int pp_nms_batch(pp_ctx *ctx, int batch, const void *net_out_dev, int dtype, int h, int w, int flip, int refine,
+                 float *peaks_dev, int *counts_dev, void *stream) {
+    int rc = check_shape(ctx, batch, dtype, h, w);
+    if (rc != PP_OK) return rc;
+    if (!net_out_dev) return PP_ERR_BAD_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float4 *pk = peaks_dev ? reinterpret_cast<float4 *>(peaks_dev) : ctx->d_peaks;
+    int *cn = counts_dev ? counts_dev : ctx->d_counts;
+    PP_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(unsigned) * (size_t)batch, st));
+    PP_HIP(ctx, pp::launch_heat_peaks(net_out_dev, dtype, batch, flip ? 2 : 1, h, w, flip, refine, 0, 0.1f, ctx->maxp, pk,
+                                      cn, ctx->d_status, st));
+    ctx->last_stream = st;
+    ctx->last_batch = batch;
+    ctx->last_peaks = pk;
+    ctx->last_counts = cn;
+    return PP_OK;
+}
+
+int pp_process_batch(pp_ctx *ctx, int batch, const void *net_out_dev, int dtype, int h, int w, int flip,
+                     int min_img_size, const int *min_img_size_dev, pp_record *records_dev, void *stream) {
+    int rc = check_shape(ctx, batch, dtype, h, w);
+    if (rc != PP_OK) return rc;
+    if (!net_out_dev) return PP_ERR_BAD_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    pp_record *rec = records_dev ? records_dev : ctx->d_records;
+    const int ns = flip ? 2 : 1;
+    PP_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(unsigned) * (size_t)batch, st));
+    PP_HIP(ctx, pp::launch_heat_peaks(net_out_dev, dtype, batch, ns, h, w, flip, 1, 0, 0.1f, ctx->maxp, ctx->d_peaks,
+                                      ctx->d_counts, ctx->d_status, st));
+    PP_HIP(ctx, pp::launch_limb_connect(net_out_dev, dtype, batch, ns, h, w, flip, ctx->maxp, ctx->cap, min_img_size,
+                                        min_img_size_dev, ctx->d_peaks, ctx->d_counts, ctx->d_conns, ctx->d_conn_counts,
+                                        ctx->d_status, st));
+    PP_HIP(ctx, pp::launch_assemble(batch, ctx->maxp, 0, ctx->d_peaks, ctx->d_counts, ctx->d_conns, ctx->d_conn_counts,
+                                    ctx->d_status, rec, st));
+    ctx->last_stream = st;
+    ctx->last_batch = batch;
+    ctx->last_peaks = ctx->d_peaks;
+    ctx->last_counts = ctx->d_counts;
+    return PP_OK;
+}
+
+int pp_read_peaks(pp_ctx *ctx, int image, float *joint_list_host, int max_rows, int *n_rows) {
+    if (!ctx || !n_rows || image < 0 || image >= ctx->last_batch || !ctx->last_peaks) return PP_ERR_BAD_ARG;
+    PP_HIP(ctx, hipStreamSynchronize(ctx->last_stream));
+    int counts[PP_NUM_PART];
+    PP_HIP(ctx, hipMemcpy(counts, ctx->last_counts + (size_t)image * PP_NUM_PART, sizeof(counts), hipMemcpyDeviceToHost));
+    std::vector<float4> pk((size_t)PP_NUM_PART * ctx->maxp);
+    PP_HIP(ctx, hipMemcpy(pk.data(), ctx->last_peaks + (size_t)image * PP_NUM_PART * ctx->maxp, pk.size() * sizeof(float4),
+                          hipMemcpyDeviceToHost));
+    int n = 0;
+    for (int part = 0; part < PP_NUM_PART; part++) {
+        const int c = counts[part] < ctx->maxp ? counts[part] : ctx->maxp;
+        for (int r = 0; r < c; r++, n++) {
+            if (joint_list_host && n < max_rows) {
+                const float4 p = pk[(size_t)part * ctx->maxp + r];
+                float *row = joint_list_host + (size_t)5 * n;
+                row[0] = p.x;
+                row[1] = p.y;
+                row[2] = p.z;
+                row[3] = (float)n;     // cnt_total_joints, utils/parse_skeletons.py:172-173
+                row[4] = (float)part;  // evaluate.py:99-103
+            }
+        }
+    }
+    *n_rows = n;
+    return PP_OK;
+}
+
+int pp_read_connections(pp_ctx *ctx, int image, int limb, float *rows_host, int max_rows, int *n_rows) {
+    if (!ctx || !n_rows || image < 0 || image >= ctx->last_batch || limb < 0 || limb >= PP_NUM_LIMB) return PP_ERR_BAD_ARG;
+    PP_HIP(ctx, hipStreamSynchronize(ctx->last_stream));
+    int n = 0;
+    PP_HIP(ctx, hipMemcpy(&n, ctx->d_conn_counts + (size_t)image * PP_NUM_LIMB + limb, sizeof(int), hipMemcpyDeviceToHost));
+    std::vector<float4> cn((size_t)ctx->maxp);
+    PP_HIP(ctx, hipMemcpy(cn.data(), ctx->d_conns + ((size_t)image * PP_NUM_LIMB + limb) * ctx->maxp,
+                          cn.size() * sizeof(float4), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n && i < max_rows && rows_host; i++) {
+        int a, b;
+        std::memcpy(&a, &cn[i].x, 4);
+        std::memcpy(&b, &cn[i].y, 4);
+        rows_host[4 * i + 0] = (float)a;
+        rows_host[4 * i + 1] = (float)b;
+        rows_host[4 * i + 2] = cn[i].z;
+        rows_host[4 * i + 3] = cn[i].w;
+    }
+    *n_rows = n;
+    return PP_OK;
+}
+
+int pp_read_records(pp_ctx *ctx, const pp_record *records_dev, pp_record *records_host, int batch, void *stream) {
+    if (!ctx || !records_host || batch <= 0 || batch > ctx->max_batch) return PP_ERR_BAD_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const pp_record *src = records_dev ? records_dev : ctx->d_records;
+    PP_HIP(ctx, hipMemcpyAsync(records_host, src, sizeof(pp_record) * (size_t)batch, hipMemcpyDeviceToHost, st));
+    PP_HIP(ctx, hipStreamSynchronize(st));
+    return PP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ drop-in
+int pp_process_paf_host(pp_ctx *ctx, int p1, int p2, int p3, const float *peaks, int f1, int f2, int f3,
+                        const float *pafmap, int min_img_size) {
+    if (!ctx || !peaks || !pafmap || p1 < 0 || p2 < 0 || p3 < 5 || f1 <= 0 || f2 <= 0 || f3 <= 0) return PP_ERR_BAD_ARG;
+    ctx->have_result = false;
+    const int maxp = ctx->maxp;
+    // pafprocess.cpp:29-41: bucket rows by part, ids in input order, x/y truncated to int
+    std::vector<float4> pk((size_t)PP_NUM_PART * maxp);
+    int counts[PP_NUM_PART] = {0};
+    int peak_cnt = 0;
+    for (int i = 0; i < p1; i++) {
+        for (int j = 0; j < p2; j++) {
+            const float *r = peaks + (size_t)p3 * (j + (size_t)p2 * i);
+            const int id = peak_cnt++;
+            const int part = (int)r[4];
+            if (part < 0 || part >= PP_NUM_PART) return PP_ERR_BAD_ARG;  // the reference writes out of bounds here
+            if (counts[part] >= maxp) return PP_ERR_OVERFLOW;
+            float4 v;
+            v.x = (float)(int)r[0];
+            v.y = (float)(int)r[1];
+            v.z = r[2];
+            std::memcpy(&v.w, &id, 4);
+            pk[(size_t)part * maxp + counts[part]++] = v;
+        }
+    }
+    // pafprocess.cpp:43-48: flattened table for the getters
+    ctx->line_x.clear();
+    ctx->line_y.clear();
+    ctx->line_s.clear();
+    for (int part = 0; part < PP_NUM_PART; part++)
+        for (int r = 0; r < counts[part]; r++) {
+            const float4 v = pk[(size_t)part * maxp + r];
+            ctx->line_x.push_back((int)v.x);
+            ctx->line_y.push_back((int)v.y);
+            ctx->line_s.push_back(v.z);
+        }
+    PP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t paf_bytes = sizeof(float) * (size_t)f1 * f2 * f3;
+    if (paf_bytes > ctx->d_paf_bytes) {
+        if (ctx->d_paf) (void)hipFree(ctx->d_paf);
+        ctx->d_paf = nullptr;
+        ctx->d_paf_bytes = 0;
+        PP_HIP(ctx, hipMalloc(&ctx->d_paf, paf_bytes));
+        ctx->d_paf_bytes = paf_bytes;
+    }
+    hipStream_t st = nullptr;
+    PP_HIP(ctx, hipMemcpyAsync(ctx->d_paf, pafmap, paf_bytes, hipMemcpyHostToDevice, st));
+    PP_HIP(ctx, hipMemcpyAsync(ctx->d_peaks, pk.data(), pk.size() * sizeof(float4), hipMemcpyHostToDevice, st));
+    PP_HIP(ctx, hipMemcpyAsync(ctx->d_counts, counts, sizeof(counts), hipMemcpyHostToDevice, st));
+    PP_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(unsigned), st));
+    PP_HIP(ctx, pp::launch_limb_connect_hwc(ctx->d_paf, f1, f2, f3, maxp, ctx->cap, min_img_size, ctx->d_peaks,
+                                            ctx->d_counts, ctx->d_conns, ctx->d_conn_counts, ctx->d_status, st));
+    PP_HIP(ctx, pp::launch_assemble(1, maxp, 1, ctx->d_peaks, ctx->d_counts, ctx->d_conns, ctx->d_conn_counts,
+                                    ctx->d_status, ctx->d_records, st));
+    PP_HIP(ctx, hipMemcpyAsync(&ctx->h_record, ctx->d_records, sizeof(pp_record), hipMemcpyDeviceToHost, st));
+    PP_HIP(ctx, hipStreamSynchronize(st));
+    ctx->last_stream = st;
+    ctx->last_batch = 1;
+    ctx->last_peaks = ctx->d_peaks;
+    ctx->last_counts = ctx->d_counts;
+    if (ctx->h_record.status & (PP_ST_HUMAN_OVERFLOW | PP_ST_SKEL_OVERFLOW | PP_ST_CAND_OVERFLOW)) return PP_ERR_OVERFLOW;
+    ctx->have_result = true;
+    return PP_OK;
+}
+
+int pp_get_num_humans(const pp_ctx *ctx) { return (ctx && ctx->have_result) ? ctx->h_record.n_humans : 0; }
+int pp_get_part_peak_id(const pp_ctx *ctx, int skeleton_id, int part_id) {
+    if (!ctx || !ctx->have_result || skeleton_id < 0 || skeleton_id >= ctx->h_record.n_humans || part_id < 0 ||
+        part_id >= PP_NUM_PART)
+        return -1;
+    return ctx->h_record.humans[skeleton_id].peak_id[part_id];
+}
+float pp_get_score(const pp_ctx *ctx, int skeleton_id) {
+    if (!ctx || !ctx->have_result || skeleton_id < 0 || skeleton_id >= ctx->h_record.n_humans) return 0.0f;
+    return ctx->h_record.humans[skeleton_id].score;
+}
+int pp_get_part_x(const pp_ctx *ctx, int cid) {
+    return (ctx && cid >= 0 && cid < (int)ctx->line_x.size()) ? ctx->line_x[cid] : 0;
+}
+int pp_get_part_y(const pp_ctx *ctx, int cid) {
+    return (ctx && cid >= 0 && cid < (int)ctx->line_y.size()) ? ctx->line_y[cid] : 0;
+}
+float pp_get_part_score(const pp_ctx *ctx, int cid) {
+    return (ctx && cid >= 0 && cid < (int)ctx->line_s.size()) ? ctx->line_s[cid] : 0.0f;
+}
+uint32_t pp_get_status(const pp_ctx *ctx) { return (ctx && ctx->have_result) ? ctx->h_record.status : 0u; }
+
+// ---- the reference's seven names, one process-wide context (pafprocess.cpp:16-17 keeps globals too)
+static pp_ctx *g_ctx = nullptr;
+static std::mutex g_mu;
+
+int process_paf(int p1, int p2, int p3, float *peaks, int f1, int f2, int f3, float *pafmap, int min_img_size) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_ctx) {
+        int dev = 0;
+        if (const char *e = std::getenv("POSEPAF_DEVICE")) dev = std::atoi(e);
+        int rc = pp_create(&g_ctx, dev, 1, 128, 128, PP_MAX_PEAKS_PER_PART_LIMIT);
+        if (rc != PP_OK) {
+            std::fprintf(stderr, "posepaf: process_paf cannot run: %s\n", pp_status_string(rc));
+            return rc;
+        }
+    }
+    int rc = pp_process_paf_host(g_ctx, p1, p2, p3, peaks, f1, f2, f3, pafmap, min_img_size);
+    if (rc != PP_OK) std::fprintf(stderr, "posepaf: process_paf failed: %s\n", pp_status_string(rc));
+    return rc;
+}
+int get_num_humans(void) { return pp_get_num_humans(g_ctx); }
+int get_part_peak_id(int skeleton_id, int part_id) { return pp_get_part_peak_id(g_ctx, skeleton_id, part_id); }
+float get_score(int skeleton_id) { return pp_get_score(g_ctx, skeleton_id); }
+int get_part_x(int cid) { return pp_get_part_x(g_ctx, cid); }
+int get_part_y(int cid) { return pp_get_part_y(g_ctx, cid); }
+float get_part_score(int cid) { return pp_get_part_score(g_ctx, cid); }
+
+}  // extern "C"

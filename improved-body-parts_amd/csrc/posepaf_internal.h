@@ -1,0 +1,35 @@
+// posepaf_internal.h -- declarations shared by the kernels and the C-ABI host code (not installed).
+#ifndef POSEPAF_INTERNAL_H
+#define POSEPAF_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/posepaf.h"
+
+namespace pp {
+
+// 160 KiB of LDS per CU (gfx950) minus room for the kernels' few static __shared__ words
+constexpr size_t kMaxDynLds = 163840 - 1024;
+hipError_t init_kernel_attributes();
+
+size_t lds_bytes_heat(int elem, int h, int w, int maxp);
+size_t lds_bytes_limb(int elem, int h, int w, int maxp, int cap);
+size_t lds_bytes_limb_hwc(int maxp, int cap);
+size_t lds_bytes_assemble(int maxp);
+
+hipError_t launch_heat_peaks(const void *net, int dtype, int batch, int n_samples, int h, int w, int flip, int refine,
+                             int nms_mode, float thr, int maxp, float4 *peaks, int *counts, unsigned *status,
+                             hipStream_t stream);
+hipError_t launch_limb_connect(const void *net, int dtype, int batch, int n_samples, int h, int w, int flip, int maxp,
+                               int cap, int min_img_size, const int *min_img_size_dev, const float4 *peaks,
+                               const int *counts, float4 *conns, int *conn_counts, unsigned *status,
+                               hipStream_t stream);
+hipError_t launch_limb_connect_hwc(const float *paf, int H, int W, int C, int maxp, int cap, int min_img_size,
+                                   const float4 *peaks, const int *counts, float4 *conns, int *conn_counts,
+                                   unsigned *status, hipStream_t stream);
+hipError_t launch_assemble(int batch, int maxp, int explicit_ids, const float4 *peaks, const int *counts,
+                           const float4 *conns, const int *conn_counts, unsigned *status, pp_record *records,
+                           hipStream_t stream);
+
+}  // namespace pp
+#endif

@@ -1,0 +1,1037 @@
+// posepaf_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for the bottom-up pose post-processing
+// path.  Three launches per batch of images, every input byte read from HBM exactly once:
+//
+//   K_A  k_heat_peaks    grid (18, B)  one 256-thread workgroup per keypoint channel
+//        flip-average the channel straight into LDS (A2), plus-shaped NMS with row-major ordered compaction
+//        by wave ballots (A3), x4 bicubic patch refinement + wave arg-max per peak (A4)
+//   K_B  k_limb_connect  grid (30, B)  one workgroup per limb channel
+//        flip-average the limb map into LDS (A2), line-integral scoring of every (a,b) peak pair with the
+//        x4 bicubic evaluated on the fly at the sampled pixel instead of materialising the 31.5 MB
+//        up-sampled map (A4'+A5), ordered compaction of accepted candidates, the reference's sort order
+//        and greedy matching (A6)
+//   K_C  k_assemble      grid (B)      one wave per image
+//        greedy person assembly with the reference's exact (bug-compatible) update rules (A7), pruning,
+//        fixed-size result records
+//
+// No MFMA anywhere: this is gather/compare/reduce work bounded by HBM.
+// Floating point: every expression mirrors the reference's operation ORDER and rounding (x86-64 g++ without
+// FMA): products and sums are kept separate with __fmul_rn/__fadd_rn and the file is built with
+// -ffp-contract=off; divisions and sqrt are the correctly rounded forms (hipcc default).
+//
+// file:line citations are relative to /root/reference.
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+
+#include "posepaf_internal.h"
+
+namespace pp {
+
+// ------------------------------------------------------------------------------------------------ tables
+// utils/pafprocess/pafprocess.h:21-27 (== config/config.py:114-121)
+__device__ const int8_t d_limb_pairs[PP_NUM_LIMB][2] = {
+    {1, 0},   {1, 14},  {1, 15},  {1, 16},  {1, 17},  {0, 14},  {0, 15},  {14, 16}, {15, 17}, {1, 2},
+    {2, 3},   {3, 4},   {1, 5},   {5, 6},   {6, 7},   {1, 8},   {8, 9},   {9, 10},  {1, 11},  {11, 12},
+    {12, 13}, {0, 2},   {0, 5},   {2, 8},   {8, 12},  {5, 11},  {11, 9},  {16, 2},  {17, 5},  {8, 11}};
+// config/config.py:150-152
+__device__ const int8_t d_flip_heat_ord[PP_NUM_HEAT] = {0, 1, 5, 6, 7, 2, 3, 4, 11, 12, 13, 8, 9, 10, 15, 14, 17, 16, 18, 19};
+__device__ const int8_t d_flip_paf_ord[PP_NUM_LIMB] = {0,  2,  1,  4,  3,  6,  5,  8,  7,  12, 13, 14, 9,  10, 11,
+                                                       18, 19, 20, 15, 16, 17, 22, 21, 25, 26, 23, 24, 28, 27, 29};
+
+// OpenCV interpolateCubic(A = -0.75) at the four fractional phases of an x4 upsample:
+// fx = (dx + 0.5)/4 - 0.5  ->  frac = .625, .875, .125, .375 for dx mod 4 = 0..3.  All sixteen values are exact
+// dyadic rationals in binary32 (no rounding in their derivation), so a literal table is bit-identical to the
+// float computation the oracle performs.
+__device__ const float d_cubic4[4][4] = {{-0.06591796875f, 0.42626953125f, 0.74951171875f, -0.10986328125f},
+                                         {-0.01025390625f, 0.11474609375f, 0.96728515625f, -0.07177734375f},
+                                         {-0.07177734375f, 0.96728515625f, 0.11474609375f, -0.01025390625f},
+                                         {-0.10986328125f, 0.74951171875f, 0.42626953125f, -0.06591796875f}};
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ float ldsf(const float *p, int i) { return p[i]; }
+__device__ __forceinline__ float ldsf(const __half *p, int i) { return __half2float(p[i]); }
+__device__ __forceinline__ unsigned long long lanemask_lt() {
+    return (1ull << (threadIdx.x & 63)) - 1ull;
+}
+
+// ------------------------------------------------------------------------------------------------ A2 loader
+// utils/parse_skeletons.py:82-103: avg[c][y][x] = (o0[c][y][x] + o1[perm(c)][y][w-1-x]) / 2 computed in the
+// array's dtype (binary16 add + binary16 halve for the AMP output, float32 otherwise), then widened.
+// The binary16 average is itself a binary16 value, so the LDS copy is kept in binary16 for that dtype
+// (half the LDS footprint, exact).  Coalesced 16-byte reads; the mirrored operand is read as the mirrored
+// 16-byte vector and reversed in registers.
+__device__ __forceinline__ __half2 avg_h2(__half2 a, __half2 b) {
+    return __hmul2(__hadd2(a, b), __float2half2_rn(0.5f));
+}
+__device__ __forceinline__ __half2 swap_h2(__half2 v) { return __lowhigh2highlow(v); }
+
+__device__ void load_channel(__half *smap, const __half *o0, const __half *o1, int h, int w, bool flip) {
+    const int npix = h * w;
+    const bool vec_ok = (w % 8 == 0) && ((reinterpret_cast<uintptr_t>(o0) & 15) == 0) &&
+                        (!flip || (reinterpret_cast<uintptr_t>(o1) & 15) == 0);
+    if (vec_ok) {
+        const int nvec = npix / 8;
+        const int vpr = w / 8;  // vectors per row
+        for (int v = threadIdx.x; v < nvec; v += kThreads) {
+            uint4 a = reinterpret_cast<const uint4 *>(o0)[v];
+            if (flip) {
+                const int y = v / vpr, vx = v - y * vpr;
+                uint4 m = reinterpret_cast<const uint4 *>(o1)[y * vpr + (vpr - 1 - vx)];
+                __half2 *ah = reinterpret_cast<__half2 *>(&a);
+                const __half2 *mh = reinterpret_cast<const __half2 *>(&m);
+                // reversed 8-vector: element j pairs with mirrored element 7-j
+                ah[0] = avg_h2(ah[0], swap_h2(mh[3]));
+                ah[1] = avg_h2(ah[1], swap_h2(mh[2]));
+                ah[2] = avg_h2(ah[2], swap_h2(mh[1]));
+                ah[3] = avg_h2(ah[3], swap_h2(mh[0]));
+            }
+            reinterpret_cast<uint4 *>(smap)[v] = a;
+        }
+    } else {
+        for (int i = threadIdx.x; i < npix; i += kThreads) {
+            __half a = o0[i];
+            if (flip) {
+                const int y = i / w, x = i - y * w;
+                a = __hmul(__hadd(a, o1[y * w + (w - 1 - x)]), __float2half(0.5f));
+            }
+            smap[i] = a;
+        }
+    }
+}
+
+__device__ void load_channel(float *smap, const float *o0, const float *o1, int h, int w, bool flip) {
+    const int npix = h * w;
+    const bool vec_ok = (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(o0) & 15) == 0) &&
+                        (!flip || (reinterpret_cast<uintptr_t>(o1) & 15) == 0);
+    if (vec_ok) {
+        const int nvec = npix / 4;
+        const int vpr = w / 4;
+        for (int v = threadIdx.x; v < nvec; v += kThreads) {
+            float4 a = reinterpret_cast<const float4 *>(o0)[v];
+            if (flip) {
+                const int y = v / vpr, vx = v - y * vpr;
+                const float4 m = reinterpret_cast<const float4 *>(o1)[y * vpr + (vpr - 1 - vx)];
+                a.x = __fadd_rn(a.x, m.w) / 2.0f;
+                a.y = __fadd_rn(a.y, m.z) / 2.0f;
+                a.z = __fadd_rn(a.z, m.y) / 2.0f;
+                a.w = __fadd_rn(a.w, m.x) / 2.0f;
+            }
+            reinterpret_cast<float4 *>(smap)[v] = a;
+        }
+    } else {
+        for (int i = threadIdx.x; i < npix; i += kThreads) {
+            float a = o0[i];
+            if (flip) {
+                const int y = i / w, x = i - y * w;
+                a = __fadd_rn(a, o1[y * w + (w - 1 - x)]) / 2.0f;
+            }
+            smap[i] = a;
+        }
+    }
+}
+
+// x4 bicubic (OpenCV INTER_CUBIC restatement, see oracle/posepaf_oracle.c) of an LDS-resident map, evaluated at
+// ONE output pixel (X, Y) of the (4*ph, 4*pw) upsample of the window [y0, y0+ph) x [x0, x0+pw) of the map;
+// taps clamp to the WINDOW (border replicate).  Horizontal pass on four rows, then vertical, products and sums
+// rounded separately, left to right.
+template <typename T>
+__device__ __forceinline__ float bicubic4_at(const T *smap, int w, int x0, int y0, int pw, int ph, int X, int Y,
+                                             const float *s_cub) {
+    const int sx = ((X + 2) >> 2) - 1, sy = ((Y + 2) >> 2) - 1;
+    const float4 ca = reinterpret_cast<const float4 *>(s_cub)[X & 3];
+    const float4 cb = reinterpret_cast<const float4 *>(s_cub)[Y & 3];
+    const int xi0 = x0 + clampi(sx - 1, 0, pw - 1), xi1 = x0 + clampi(sx, 0, pw - 1);
+    const int xi2 = x0 + clampi(sx + 1, 0, pw - 1), xi3 = x0 + clampi(sx + 2, 0, pw - 1);
+    float hrow[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const T *row = smap + (y0 + clampi(sy - 1 + j, 0, ph - 1)) * w;
+        float v = __fmul_rn(ldsf(row, xi0), ca.x);
+        v = __fadd_rn(v, __fmul_rn(ldsf(row, xi1), ca.y));
+        v = __fadd_rn(v, __fmul_rn(ldsf(row, xi2), ca.z));
+        v = __fadd_rn(v, __fmul_rn(ldsf(row, xi3), ca.w));
+        hrow[j] = v;
+    }
+    float v = __fmul_rn(hrow[0], cb.x);
+    v = __fadd_rn(v, __fmul_rn(hrow[1], cb.y));
+    v = __fadd_rn(v, __fmul_rn(hrow[2], cb.z));
+    v = __fadd_rn(v, __fmul_rn(hrow[3], cb.w));
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------ K_A
+// LDS layout (dynamic): [map: h*w T][cubic 16 f32][chunk masks u64 x nchunks][chunk offsets i32 x (nchunks+1)]
+//                       [peak linear index i32 x maxp]
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_heat_peaks(const T *__restrict__ net, int n_samples, int h, int w,
+                                                         int flip, int refine, int nms_mode, float thr, int maxp,
+                                                         float4 *__restrict__ peaks, int *__restrict__ counts,
+                                                         unsigned *__restrict__ status) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int part = blockIdx.x, img = blockIdx.y;
+    const int npix = h * w;
+    const int nchunks = (npix + 63) >> 6;
+    size_t off = 0;
+    T *smap = reinterpret_cast<T *>(lds_raw);
+    off += (sizeof(T) * (size_t)npix + 15) & ~(size_t)15;
+    float *s_cub = reinterpret_cast<float *>(lds_raw + off);
+    off += 64;
+    unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(lds_raw + off);
+    off += sizeof(unsigned long long) * (size_t)nchunks;
+    int *s_off = reinterpret_cast<int *>(lds_raw + off);
+    off += sizeof(int) * (size_t)(nchunks + 4);
+    int *s_pk = reinterpret_cast<int *>(lds_raw + off);
+    __shared__ int s_wsum[kWaves];
+    __shared__ int s_total;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 16) s_cub[threadIdx.x] = d_cubic4[threadIdx.x >> 2][threadIdx.x & 3];
+
+    const size_t plane = (size_t)npix;
+    const T *o0 = net + ((size_t)img * n_samples * PP_NUM_CH + PP_NUM_LIMB + part) * plane;
+    const T *o1 = net + (((size_t)img * n_samples + 1) * PP_NUM_CH + PP_NUM_LIMB + d_flip_heat_ord[part]) * plane;
+    load_channel(smap, o0, o1, h, w, flip != 0);
+    __syncthreads();
+
+    // ---- A3: local maxima, 64 consecutive row-major pixels per wave step, one ballot each
+    for (int chunk = wave; chunk < nchunks; chunk += kWaves) {
+        const int i = (chunk << 6) + lane;
+        bool pk = false;
+        if (i < npix) {
+            const float v = ldsf(smap, i);
+            const bool above = nms_mode == 0 ? (v > thr) : (v >= thr);  // parse_skeletons.py:116 / util.py:184
+            if (above) {
+                const int y = i / w, x = i - y * w;
+                pk = true;
+                if (y > 0 && ldsf(smap, i - w) > v) pk = false;
+                if (y < h - 1 && ldsf(smap, i + w) > v) pk = false;
+                if (x > 0 && ldsf(smap, i - 1) > v) pk = false;
+                if (x < w - 1 && ldsf(smap, i + 1) > v) pk = false;
+                if (nms_mode != 0) {  // full 3x3 window (utils/util.py:181-184)
+                    if (y > 0 && x > 0 && ldsf(smap, i - w - 1) > v) pk = false;
+                    if (y > 0 && x < w - 1 && ldsf(smap, i - w + 1) > v) pk = false;
+                    if (y < h - 1 && x > 0 && ldsf(smap, i + w - 1) > v) pk = false;
+                    if (y < h - 1 && x < w - 1 && ldsf(smap, i + w + 1) > v) pk = false;
+                }
+            }
+        }
+        const unsigned long long m = __ballot(pk);
+        if (lane == 0) s_mask[chunk] = m;
+    }
+    __syncthreads();
+
+    // ---- exclusive scan of the per-chunk populations (np.nonzero order == ascending linear index)
+    {
+        const int cpt = (nchunks + kThreads - 1) / kThreads;  // chunks per thread
+        const int c0 = threadIdx.x * cpt;
+        int local = 0;
+        for (int c = c0; c < c0 + cpt && c < nchunks; c++) local += __popcll(s_mask[c]);
+        int incl = local;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int n = __shfl_up(incl, d);
+            if (lane >= d) incl += n;
+        }
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int k = 0; k < wave; k++) base += s_wsum[k];
+        int run = base + incl - local;
+        for (int c = c0; c < c0 + cpt && c < nchunks; c++) {
+            s_off[c] = run;
+            run += __popcll(s_mask[c]);
+        }
+        if (threadIdx.x == kThreads - 1) s_total = run;
+        __syncthreads();
+    }
+    const int total = s_total;
+    const int kept = total < maxp ? total : maxp;
+    for (int chunk = wave; chunk < nchunks; chunk += kWaves) {
+        const unsigned long long m = s_mask[chunk];
+        if ((m >> lane) & 1ull) {
+            const int rank = s_off[chunk] + __popcll(m & lanemask_lt());
+            if (rank < maxp) s_pk[rank] = (chunk << 6) + lane;
+        }
+    }
+    __syncthreads();
+
+    // ---- A4: per-peak refinement, one wave per peak
+    float4 *out = peaks + ((size_t)img * PP_NUM_PART + part) * maxp;
+    for (int p = wave; p < kept; p += kWaves) {
+        const int i = s_pk[p];
+        const int py = i / w, px = i - py * w;
+        float ox, oy, score;
+        if (refine) {
+            const int x_min = px - 2 < 0 ? 0 : px - 2, y_min = py - 2 < 0 ? 0 : py - 2;  // win_size 2, :135,:143-144
+            const int x_max = px + 2 > w - 1 ? w - 1 : px + 2, y_max = py + 2 > h - 1 ? h - 1 : py + 2;
+            const int pw = x_max - x_min + 1, ph = y_max - y_min + 1;
+            const int uw = pw * 4, n = uw * ph * 4;
+            float best_v = -INFINITY;
+            int best_k = 0x7fffffff;
+            for (int k = lane; k < n; k += 64) {
+                const int row = k / uw, col = k - row * uw;
+                const float v = bicubic4_at(smap, w, x_min, y_min, pw, ph, col, row, s_cub);
+                if (v > best_v || best_k == 0x7fffffff) {
+                    best_v = v;
+                    best_k = k;
+                }
+            }
+            // arg-max with first-occurrence tie-break (ndarray.argmax, :156)
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const float ov = __shfl_xor(best_v, d);
+                const int ok = __shfl_xor(best_k, d);
+                if (ok != 0x7fffffff && (best_k == 0x7fffffff || ov > best_v || (ov == best_v && ok < best_k))) {
+                    best_v = ov;
+                    best_k = ok;
+                }
+            }
+            const int row = best_k / uw, col = best_k - row * uw;
+            ox = (float)(4 * x_min + col);  // :164-171 collapses to stride*x_min + col (exact integer)
+            oy = (float)(4 * y_min + row);
+            score = best_v;
+        } else {
+            ox = __fadd_rn(__fmul_rn(__fadd_rn((float)px, 0.5f), 4.0f), -0.5f);  // compute_resized_coords, :122-123
+            oy = __fadd_rn(__fmul_rn(__fadd_rn((float)py, 0.5f), 4.0f), -0.5f);
+            score = ldsf(smap, i);
+        }
+        if (lane == 0) out[p] = make_float4(ox, oy, score, 0.0f);
+    }
+    if (threadIdx.x == 0) {
+        counts[img * PP_NUM_PART + part] = total;
+        if (total > maxp) atomicOr(&status[img], PP_ST_PEAK_OVERFLOW);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K_B
+// Samplers.  Both return the value the reference reads at PAF(y, x, limb) (pafprocess.cpp:9, :322).
+template <typename T>
+struct LdsBicubicSampler {  // fused path: the (4h, 4w) upsample is never materialised
+    const T *smap;
+    const float *s_cub;
+    int h, w;
+    __device__ __forceinline__ float at(int X, int Y) const {
+        X = clampi(X, 0, 4 * w - 1);  // the reference does not bounds-check; in-range peaks never leave the map
+        Y = clampi(Y, 0, 4 * h - 1);
+        return bicubic4_at(smap, w, 0, 0, w, h, X, Y, s_cub);
+    }
+};
+struct GlobalHwcSampler {  // drop-in path: caller supplies the already up-sampled (H, W, C) map
+    const float *paf;
+    int H, W, C, limb;
+    __device__ __forceinline__ float at(int X, int Y) const {
+        X = clampi(X, 0, W - 1);
+        Y = clampi(Y, 0, H - 1);
+        return paf[((size_t)Y * W + X) * C + limb];
+    }
+};
+
+struct SortElem {
+    float key;
+    int gen;
+};
+
+// libstdc++ std::sort (introsort, threshold 16, depth limit 2*floor(log2 n), heapsort fallback, final
+// insertion sort) with the reference's comparator a.overall_score >= b.overall_score
+// (pafprocess.cpp:109, :333-335), executed by ONE lane on an LDS array.  Tied keys are common on this path
+// (duplicate peaks) and the order among ties decides the greedy matching, so the algorithm itself is part of
+// the result; it is restated step for step (see oracle/posepaf_oracle.c for the same restatement in C).
+// Scans that libstdc++ leaves unguarded stop at the array bounds here and set *oob.
+struct StdSortGE {
+    SortElem *b;
+    int n;
+    bool oob;
+    __device__ __forceinline__ static bool ge(const SortElem &a, const SortElem &c) { return a.key >= c.key; }
+    __device__ __forceinline__ void swp(int i, int j) {
+        const SortElem t = b[i];
+        b[i] = b[j];
+        b[j] = t;
+    }
+    __device__ void unguarded_linear_insert(int last) {
+        const SortElem val = b[last];
+        int next = last - 1;
+        while (true) {
+            if (next < 0) {
+                oob = true;
+                break;
+            }
+            const SortElem nx = b[next];
+            if (!ge(val, nx)) break;
+            b[last] = nx;
+            last = next;
+            --next;
+        }
+        b[last] = val;
+    }
+    __device__ void insertion_sort(int first, int last) {
+        if (first == last) return;
+        for (int i = first + 1; i != last; ++i) {
+            const SortElem val = b[i];
+            if (ge(val, b[first])) {
+                for (int k = i; k > first; --k) b[k] = b[k - 1];
+                b[first] = val;
+            } else {
+                unguarded_linear_insert(i);
+            }
+        }
+    }
+    __device__ void push_heap(int first, int hole, int top, SortElem value) {
+        int parent = (hole - 1) / 2;
+        while (hole > top && ge(b[first + parent], value)) {
+            b[first + hole] = b[first + parent];
+            hole = parent;
+            parent = (hole - 1) / 2;
+        }
+        b[first + hole] = value;
+    }
+    __device__ void adjust_heap(int first, int hole, int len, SortElem value) {
+        const int top = hole;
+        int child = hole;
+        while (child < (len - 1) / 2) {
+            child = 2 * (child + 1);
+            if (ge(b[first + child], b[first + child - 1])) child--;
+            b[first + hole] = b[first + child];
+            hole = child;
+        }
+        if ((len & 1) == 0 && child == (len - 2) / 2) {
+            child = 2 * (child + 1);
+            b[first + hole] = b[first + child - 1];
+            hole = child - 1;
+        }
+        push_heap(first, hole, top, value);
+    }
+    __device__ void heapsort(int first, int last) {
+        const int len = last - first;
+        if (len >= 2) {
+            int parent = (len - 2) / 2;
+            while (true) {
+                adjust_heap(first, parent, len, b[first + parent]);
+                if (parent == 0) break;
+                parent--;
+            }
+        }
+        while (last - first > 1) {
+            --last;
+            const SortElem v = b[last];
+            b[last] = b[first];
+            adjust_heap(first, 0, last - first, v);
+        }
+    }
+    __device__ void move_median_to_first(int result, int a, int m, int c) {
+        const SortElem va = b[a], vm = b[m], vc = b[c];
+        if (ge(va, vm)) {
+            if (ge(vm, vc)) swp(result, m);
+            else if (ge(va, vc)) swp(result, c);
+            else swp(result, a);
+        } else if (ge(va, vc)) swp(result, a);
+        else if (ge(vm, vc)) swp(result, c);
+        else swp(result, m);
+    }
+    __device__ int unguarded_partition(int first, int last, int pivot) {
+        const SortElem pv = b[pivot];  // the pivot slot is never written during the partition
+        while (true) {
+            while (true) {
+                if (first >= n) {
+                    oob = true;
+                    break;
+                }
+                if (!ge(b[first], pv)) break;
+                ++first;
+            }
+            --last;
+            while (true) {
+                if (last < 0) {
+                    oob = true;
+                    break;
+                }
+                if (!ge(pv, b[last])) break;
+                --last;
+            }
+            if (!(first < last)) return first;
+            swp(first, last);
+            ++first;
+        }
+    }
+    __device__ void run() {
+        oob = false;
+        if (n <= 0) return;
+        int lg = 0;
+        while ((1 << (lg + 1)) <= n) lg++;
+        // __introsort_loop with its tail recursion made explicit: recurse on [cut, last), loop on [first, cut)
+        int stack_first[40], stack_last[40], stack_depth[40];
+        int sp = 0;
+        stack_first[0] = 0;
+        stack_last[0] = n;
+        stack_depth[0] = 2 * lg;
+        sp = 1;
+        while (sp > 0) {
+            --sp;
+            const int first = stack_first[sp];
+            int last = stack_last[sp];
+            int depth = stack_depth[sp];
+            // libstdc++ handles the right part FIRST (recursive call) and then continues with the left part.
+            // The two parts are disjoint, so the order in which they are processed does not change the result.
+            while (last - first > 16) {
+                if (depth == 0) {
+                    heapsort(first, last);
+                    break;
+                }
+                --depth;
+                const int mid = first + (last - first) / 2;
+                move_median_to_first(first, first + 1, mid, last - 1);
+                int cut = unguarded_partition(first + 1, last, first);
+                if (cut > last) cut = last;  // only after an out-of-bounds scan
+                if (sp < 40) {
+                    stack_first[sp] = cut;
+                    stack_last[sp] = last;
+                    stack_depth[sp] = depth;
+                    ++sp;
+                }
+                last = cut;
+            }
+        }
+        if (n > 16) {  // __final_insertion_sort
+            insertion_sort(0, 16);
+            for (int i = 16; i < n; ++i) unguarded_linear_insert(i);
+        } else {
+            insertion_sort(0, n);
+        }
+    }
+};
+
+// Scores one (a, b) peak pair: pafprocess.cpp:66-106 + get_paf_scores :311-327.
+template <typename Sampler>
+__device__ __forceinline__ bool score_pair(const Sampler &smp, int ax, int ay, float as, int bx, int by, float bs,
+                                           int min_img_size, float *c2_out, float *overall_out, float *len_out) {
+    const int dxi = bx - ax, dyi = by - ay;
+    const float vx = (float)dxi, vy = (float)dyi;
+    const float vec_length = sqrtf(__fadd_rn(__fmul_rn(vx, vx), __fmul_rn(vy, vy)));  // :70
+    if ((double)vec_length < 1e-12) return false;                                      // :71
+    int num_steps = (int)((double)__fadd_rn(vec_length, 1.0f) + 0.5);                  // round2int, :73, :329
+    if (num_steps > 20) num_steps = 20;                                                // STEP_PAF
+    const float step_x = vx / (float)(num_steps - 1);                                  // :314-315
+    const float step_y = vy / (float)(num_steps - 1);
+    float scores = 0.0f;
+    int criterion1 = 0;
+    for (int i = 0; i < num_steps; i++) {
+        const int lx = (int)((double)__fadd_rn((float)ax, __fmul_rn((float)i, step_x)) + 0.5);  // :318-319
+        const int ly = (int)((double)__fadd_rn((float)ay, __fmul_rn((float)i, step_y)) + 0.5);
+        const float s = smp.at(lx, ly);
+        scores = __fadd_rn(scores, s);  // :86
+        if (s > 0.1f) criterion1 += 1;  // THRESH_PAF_SCORE
+    }
+    double prior = 0.5 * (double)min_img_size / (double)vec_length - 1.0;  // :92
+    if (!(prior < 0.0)) prior = 0.0;                                        // std::min(0.0, prior)
+    const float criterion2 = (float)((double)(scores / (float)num_steps) + prior);
+    const float min_num_steps = __fmul_rn((float)num_steps, 0.8f);  // :93 THRESH_PAF_STEP_RATIO
+    if (!((float)criterion1 > min_num_steps && criterion2 > 0.0f)) return false;  // :95
+    // :96-98  PAF_OUT_WEIGHTS = {0.5, 0.25, 0.25}
+    *overall_out = __fadd_rn(__fadd_rn(__fmul_rn(0.5f, criterion2), __fmul_rn(0.25f, as)), __fmul_rn(0.25f, bs));
+    *c2_out = criterion2;
+    *len_out = vec_length;
+    return true;
+}
+
+// Shared tail of K_B: ordered candidate compaction, the reference's sort, greedy matching (pafprocess.cpp:108-130)
+struct LimbLds {
+    int *ax, *ay, *bx, *by;
+    float *as, *bs;
+    SortElem *sort;      // [cap]
+    float *c_score;      // [cap]  criterion2
+    float *c_len;        // [cap]
+    unsigned *c_idx;     // [cap]  ia | ib << 16
+};
+
+template <typename Sampler>
+__device__ void connect_limb(const Sampler &smp, const LimbLds &L, int nA, int nB, int cap, int maxp, int min_img_size,
+                             float4 *__restrict__ conn_out, int *__restrict__ conn_count,
+                             unsigned *__restrict__ status_word) {
+    __shared__ int s_wcnt[2][kWaves];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int npairs = nA * nB;
+    int ncand = 0;  // uniform across the workgroup
+    int buf = 0;
+    for (int base = 0; base < npairs; base += kThreads, buf ^= 1) {
+        const int p = base + threadIdx.x;
+        bool ok = false;
+        float c2 = 0.f, overall = 0.f, len = 0.f;
+        int ia = 0, ib = 0;
+        if (p < npairs) {
+            ia = p / nB;  // generation order of the reference: a outer, b inner (:61-64)
+            ib = p - ia * nB;
+            ok = score_pair(smp, L.ax[ia], L.ay[ia], L.as[ia], L.bx[ib], L.by[ib], L.bs[ib], min_img_size, &c2, &overall,
+                            &len);
+        }
+        const unsigned long long m = __ballot(ok);
+        if (lane == 0) s_wcnt[buf][wave] = __popcll(m);
+        __syncthreads();
+        int before = 0, all = 0;
+#pragma unroll
+        for (int k = 0; k < kWaves; k++) {
+            const int c = s_wcnt[buf][k];
+            if (k < wave) before += c;
+            all += c;
+        }
+        if (ok) {
+            const int pos = ncand + before + __popcll(m & lanemask_lt());
+            if (pos < cap) {
+                L.sort[pos].key = overall;
+                L.sort[pos].gen = pos;
+                L.c_score[pos] = c2;
+                L.c_len[pos] = len;
+                L.c_idx[pos] = (unsigned)ia | ((unsigned)ib << 16);
+            }
+        }
+        ncand += all;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned st = 0;
+        if (ncand > cap) {
+            st |= PP_ST_CAND_OVERFLOW;
+            ncand = cap;
+        }
+        StdSortGE srt;
+        srt.b = L.sort;
+        srt.n = ncand;
+        srt.run();
+        if (srt.oob) st |= PP_ST_SORT_UNDEFINED;
+        // greedy pick, :111-129
+        const int max_conn = nA < nB ? nA : nB;
+        unsigned long long ua0 = 0, ua1 = 0, ub0 = 0, ub1 = 0;
+        int ncn = 0;
+        for (int k = 0; k < ncand && ncn < max_conn; k++) {
+            const int g = L.sort[k].gen;
+            const unsigned idx = L.c_idx[g];
+            const int ia = (int)(idx & 0xffffu), ib = (int)(idx >> 16);
+            const unsigned long long ma = 1ull << (ia & 63), mb = 1ull << (ib & 63);
+            const bool a_used = ((ia < 64 ? ua0 : ua1) & ma) != 0;
+            const bool b_used = ((ib < 64 ? ub0 : ub1) & mb) != 0;
+            if (!a_used && !b_used) {
+                if (ia < 64) ua0 |= ma; else ua1 |= ma;
+                if (ib < 64) ub0 |= mb; else ub1 |= mb;
+                conn_out[ncn] = make_float4(__int_as_float(ia), __int_as_float(ib), L.c_score[g], L.c_len[g]);
+                ncn++;
+            }
+        }
+        *conn_count = ncn;
+        if (st) atomicOr(status_word, st);
+    }
+    (void)maxp;
+}
+
+// LDS layout (dynamic): [map h*w T][cubic 16 f32][peaks: 6 arrays x maxp][sort cap x 8][c_score cap][c_len cap][c_idx cap]
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_limb_connect(const T *__restrict__ net, int n_samples, int h, int w,
+                                                           int flip, int maxp, int cap, int min_img_size,
+                                                           const int *__restrict__ min_img_size_dev,
+                                                           const float4 *__restrict__ peaks,
+                                                           const int *__restrict__ counts, float4 *__restrict__ conns,
+                                                           int *__restrict__ conn_counts, unsigned *__restrict__ status) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int limb = blockIdx.x, img = blockIdx.y;
+    const int pa = d_limb_pairs[limb][0], pb = d_limb_pairs[limb][1];
+    int nA = counts[img * PP_NUM_PART + pa], nB = counts[img * PP_NUM_PART + pb];
+    nA = nA < maxp ? nA : maxp;
+    nB = nB < maxp ? nB : maxp;
+    int *cc = conn_counts + img * PP_NUM_LIMB + limb;
+    if (nA == 0 || nB == 0) {  // no candidate pairs: no connections (pafprocess.cpp:56-58, :111)
+        if (threadIdx.x == 0) *cc = 0;
+        return;
+    }
+    const int npix = h * w;
+    size_t off = 0;
+    T *smap = reinterpret_cast<T *>(lds_raw);
+    off += (sizeof(T) * (size_t)npix + 15) & ~(size_t)15;
+    float *s_cub = reinterpret_cast<float *>(lds_raw + off);
+    off += 64;
+    LimbLds L;
+    L.ax = reinterpret_cast<int *>(lds_raw + off); off += 4 * (size_t)maxp;
+    L.ay = reinterpret_cast<int *>(lds_raw + off); off += 4 * (size_t)maxp;
+    L.bx = reinterpret_cast<int *>(lds_raw + off); off += 4 * (size_t)maxp;
+    L.by = reinterpret_cast<int *>(lds_raw + off); off += 4 * (size_t)maxp;
+    L.as = reinterpret_cast<float *>(lds_raw + off); off += 4 * (size_t)maxp;
+    L.bs = reinterpret_cast<float *>(lds_raw + off); off += 4 * (size_t)maxp;
+    off = (off + 7) & ~(size_t)7;
+    L.sort = reinterpret_cast<SortElem *>(lds_raw + off); off += 8 * (size_t)cap;
+    L.c_score = reinterpret_cast<float *>(lds_raw + off); off += 4 * (size_t)cap;
+    L.c_len = reinterpret_cast<float *>(lds_raw + off); off += 4 * (size_t)cap;
+    L.c_idx = reinterpret_cast<unsigned *>(lds_raw + off);
+
+    if (threadIdx.x < 16) s_cub[threadIdx.x] = d_cubic4[threadIdx.x >> 2][threadIdx.x & 3];
+    const float4 *pka = peaks + ((size_t)img * PP_NUM_PART + pa) * maxp;
+    const float4 *pkb = peaks + ((size_t)img * PP_NUM_PART + pb) * maxp;
+    for (int i = threadIdx.x; i < nA; i += kThreads) {
+        const float4 p = pka[i];
+        L.ax[i] = (int)p.x;  // Peak.x/y are ints: truncation (pafprocess.cpp:35-36)
+        L.ay[i] = (int)p.y;
+        L.as[i] = p.z;
+    }
+    for (int i = threadIdx.x; i < nB; i += kThreads) {
+        const float4 p = pkb[i];
+        L.bx[i] = (int)p.x;
+        L.by[i] = (int)p.y;
+        L.bs[i] = p.z;
+    }
+    const size_t plane = (size_t)npix;
+    const T *o0 = net + ((size_t)img * n_samples * PP_NUM_CH + limb) * plane;
+    const T *o1 = net + (((size_t)img * n_samples + 1) * PP_NUM_CH + d_flip_paf_ord[limb]) * plane;
+    load_channel(smap, o0, o1, h, w, flip != 0);
+    __syncthreads();
+
+    LdsBicubicSampler<T> smp{smap, s_cub, h, w};
+    const int mis = min_img_size_dev ? min_img_size_dev[img] : min_img_size;
+    connect_limb(smp, L, nA, nB, cap, maxp, mis, conns + ((size_t)img * PP_NUM_LIMB + limb) * maxp, cc, status + img);
+}
+
+// Drop-in path: the caller's (H, W, C) up-sampled map lives in global memory (uploaded by process_paf)
+__global__ __launch_bounds__(kThreads) void k_limb_connect_hwc(const float *__restrict__ paf, int H, int W, int C,
+                                                               int maxp, int cap, int min_img_size,
+                                                               const float4 *__restrict__ peaks,
+                                                               const int *__restrict__ counts,
+                                                               float4 *__restrict__ conns, int *__restrict__ conn_counts,
+                                                               unsigned *__restrict__ status) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int limb = blockIdx.x;
+    const int pa = d_limb_pairs[limb][0], pb = d_limb_pairs[limb][1];
+    int nA = counts[pa], nB = counts[pb];
+    nA = nA < maxp ? nA : maxp;
+    nB = nB < maxp ? nB : maxp;
+    int *cc = conn_counts + limb;
+    if (nA == 0 || nB == 0 || limb >= C) {
+        if (threadIdx.x == 0) *cc = 0;
+        return;
+    }
+    size_t off = 0;
+    LimbLds L;
+    L.ax = reinterpret_cast<int *>(lds_raw + off); off += 4 * (size_t)maxp;
+    L.ay = reinterpret_cast<int *>(lds_raw + off); off += 4 * (size_t)maxp;
+    L.bx = reinterpret_cast<int *>(lds_raw + off); off += 4 * (size_t)maxp;
+    L.by = reinterpret_cast<int *>(lds_raw + off); off += 4 * (size_t)maxp;
+    L.as = reinterpret_cast<float *>(lds_raw + off); off += 4 * (size_t)maxp;
+    L.bs = reinterpret_cast<float *>(lds_raw + off); off += 4 * (size_t)maxp;
+    off = (off + 7) & ~(size_t)7;
+    L.sort = reinterpret_cast<SortElem *>(lds_raw + off); off += 8 * (size_t)cap;
+    L.c_score = reinterpret_cast<float *>(lds_raw + off); off += 4 * (size_t)cap;
+    L.c_len = reinterpret_cast<float *>(lds_raw + off); off += 4 * (size_t)cap;
+    L.c_idx = reinterpret_cast<unsigned *>(lds_raw + off);
+    const float4 *pka = peaks + (size_t)pa * maxp;
+    const float4 *pkb = peaks + (size_t)pb * maxp;
+    for (int i = threadIdx.x; i < nA; i += kThreads) {
+        const float4 p = pka[i];
+        L.ax[i] = (int)p.x;
+        L.ay[i] = (int)p.y;
+        L.as[i] = p.z;
+    }
+    for (int i = threadIdx.x; i < nB; i += kThreads) {
+        const float4 p = pkb[i];
+        L.bx[i] = (int)p.x;
+        L.by[i] = (int)p.y;
+        L.bs[i] = p.z;
+    }
+    __syncthreads();
+    GlobalHwcSampler smp{paf, H, W, C, limb};
+    connect_limb(smp, L, nA, nB, cap, maxp, min_img_size, conns + (size_t)limb * maxp, cc, status);
+}
+
+// ------------------------------------------------------------------------------------------------ K_C
+// One wave per image.  Skeleton table in LDS: entry [s][k], k in [0,18) = {peak id, limb score},
+// k = 18 = {-, total score}, k = 19 = {part count, longest limb} (pafprocess.h:36-45, pafprocess.cpp:11-12).
+// The scan over live skeletons (pafprocess.cpp:143-150) is done by the 64 lanes with ballots; the matched
+// skeleton(s) are then updated by lane 0 with the reference's exact statement order.
+constexpr int kMaxSkel = 256;
+constexpr int kSkelStride = 20;
+
+__global__ __launch_bounds__(64) void k_assemble(int maxp, int explicit_ids, const float4 *__restrict__ peaks,
+                                                 const int *__restrict__ counts, const float4 *__restrict__ conns,
+                                                 const int *__restrict__ conn_counts, unsigned *__restrict__ status,
+                                                 pp_record *__restrict__ records) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int img = blockIdx.x, lane = threadIdx.x;
+    const int ntab = PP_NUM_PART * maxp;
+    int *sk_id = reinterpret_cast<int *>(lds_raw);                       // [kMaxSkel][20]
+    float *sk_sc = reinterpret_cast<float *>(sk_id + kMaxSkel * kSkelStride);
+    int *line_x = reinterpret_cast<int *>(sk_sc + kMaxSkel * kSkelStride);  // peak_infos_line, bucket order
+    int *line_y = line_x + ntab;
+    float *line_s = reinterpret_cast<float *>(line_y + ntab);
+    int *ids = reinterpret_cast<int *>(line_s + ntab);                   // [18][maxp] peak id of (part, rank)
+    __shared__ int s_off[PP_NUM_PART + 1];
+    __shared__ int s_cnt[PP_NUM_PART];
+    __shared__ int s_merge;
+
+    const int *cnt_g = counts + img * PP_NUM_PART;
+    const float4 *pk_g = peaks + (size_t)img * PP_NUM_PART * maxp;
+    if (lane == 0) {
+        int run = 0;
+        for (int k = 0; k < PP_NUM_PART; k++) {
+            int c = cnt_g[k];
+            c = c < maxp ? c : maxp;
+            s_cnt[k] = c;
+            s_off[k] = run;
+            run += c;
+        }
+        s_off[PP_NUM_PART] = run;
+    }
+    __syncthreads();
+    const int n_peaks = s_off[PP_NUM_PART];
+    for (int part = 0; part < PP_NUM_PART; part++) {  // pafprocess.cpp:43-48 flatten in part order
+        const int c = s_cnt[part], o = s_off[part];
+        for (int r = lane; r < c; r += 64) {
+            const float4 p = pk_g[(size_t)part * maxp + r];
+            line_x[o + r] = (int)p.x;
+            line_y[o + r] = (int)p.y;
+            line_s[o + r] = p.z;
+            ids[part * maxp + r] = explicit_ids ? __float_as_int(p.w) : (o + r);  // :34 ids follow input order
+        }
+    }
+    __syncthreads();
+
+    int nskel = 0;  // uniform
+    unsigned st = 0;
+    for (int limb = 0; limb < PP_NUM_LIMB; limb++) {
+        const int part1 = d_limb_pairs[limb][0], part2 = d_limb_pairs[limb][1];
+        const int nconn = conn_counts[img * PP_NUM_LIMB + limb];
+        const float4 *cn_g = conns + ((size_t)img * PP_NUM_LIMB + limb) * maxp;
+        for (int ci = 0; ci < nconn; ci++) {
+            const float4 cn = cn_g[ci];
+            const int cid1 = __float_as_int(cn.x), cid2 = __float_as_int(cn.y);
+            const float c_score = cn.z, c_len = cn.w;
+            const int id1 = ids[part1 * maxp + cid1], id2 = ids[part2 * maxp + cid2];
+            // ---- :143-150 scan all live skeletons
+            int num_found = 0, idx1 = 0, idx2 = 0;
+            for (int base = 0; base < nskel; base += 64) {
+                const int s = base + lane;
+                bool hit = false;
+                if (s < nskel) hit = (sk_id[s * kSkelStride + part1] == id1) || (sk_id[s * kSkelStride + part2] == id2);
+                unsigned long long m = __ballot(hit);
+                while (m) {
+                    const int l = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    if (num_found == 0) idx1 = base + l;
+                    if (num_found == 1) idx2 = base + l;
+                    num_found++;
+                }
+            }
+            // pl[id].score with the reference's indexing BY ID into the bucket-ordered line (:162)
+            const float ps1 = (id1 >= 0 && id1 < n_peaks) ? line_s[id1] : 0.0f;
+            const float ps2 = (id2 >= 0 && id2 < n_peaks) ? line_s[id2] : 0.0f;
+            if (num_found == 1) {  // :152-180
+                if (lane == 0) {
+                    int *i1 = sk_id + idx1 * kSkelStride;
+                    float *f1 = sk_sc + idx1 * kSkelStride;
+                    const int min_len = (int)__fmul_rn(f1[19], 16.0f);  // :154 int truncation of length*LIMB_LENGTH_RATE
+                    const int cur_id = i1[part2];
+                    const float cur_sc = f1[part2];
+                    if (cur_id == -1 && (float)min_len > c_len) {
+                        i1[part2] = id2;
+                        f1[part2] = c_score;
+                        i1[19] += 1;
+                        f1[19] = f1[19] < c_len ? c_len : f1[19];
+                        f1[18] = __fadd_rn(f1[18], __fadd_rn(ps2, c_score));
+                    } else if ((cur_id != id2 && cur_sc <= c_score && (float)min_len > c_len) ||
+                               (cur_id == id2 && cur_sc <= c_score)) {
+                        // :163-180 the id/score are overwritten BEFORE the subtraction, so -= and += use the same
+                        // operands: total = (total - t) + t with t = pl[id2].score + conn.score
+                        i1[part2] = id2;
+                        f1[part2] = c_score;
+                        const float t = __fadd_rn(ps2, c_score);
+                        f1[18] = __fadd_rn(__fadd_rn(f1[18], -t), t);
+                        f1[19] = f1[19] < c_len ? c_len : f1[19];
+                    }
+                }
+                __syncthreads();
+            } else if (num_found == 2) {  // :182-256
+                if (lane == 0) {
+                    int *i1 = sk_id + idx1 * kSkelStride, *i2 = sk_id + idx2 * kSkelStride;
+                    float *f1 = sk_sc + idx1 * kSkelStride, *f2 = sk_sc + idx2 * kSkelStride;
+                    const int min_len = (int)__fmul_rn(f1[19], 16.0f);
+                    bool is_member = false;
+                    float min1 = 0.0f, min2 = 0.0f;
+                    for (int kp = 0; kp < PP_NUM_PART; kp++) {
+                        const bool a1 = i1[kp] > 0, a2 = i2[kp] > 0;  // :200-201 id 0 counts as unassigned
+                        if (a1) min1 = (min1 == 0.0f) ? f1[kp] : (f1[kp] < min1 ? f1[kp] : min1);
+                        if (a2) min2 = (min2 == 0.0f) ? f2[kp] : (f2[kp] < min2 ? f2[kp] : min2);
+                        if (a1 && a2) is_member = true;
+                    }
+                    int merge = 0;
+                    if (!is_member) {
+                        const float lim = __fmul_rn((min2 < min1 ? min2 : min1), 0.7f);  // :220
+                        if (c_score >= lim || c_len < (float)min_len) {                   // :221 OR
+                            for (int kp = 0; kp < PP_NUM_PART; kp++) {
+                                i1[kp] += (i2[kp] + 1);
+                                f1[kp] = __fadd_rn(f1[kp], __fadd_rn(f2[kp], 1.0f));
+                            }
+                            i1[19] += i2[19];
+                            f1[19] = f1[19] < c_len ? c_len : f1[19];
+                            f1[18] = __fadd_rn(f1[18], __fadd_rn(f2[18], c_score));
+                            merge = 1;
+                        }
+                    }
+                    s_merge = merge;
+                }
+                __syncthreads();
+                if (s_merge) {  // skeletons.erase(begin + idx2): shift the tail down one slot (:228)
+                    for (int s = idx2; s < nskel - 1; s++) {
+                        if (lane < kSkelStride) {
+                            sk_id[s * kSkelStride + lane] = sk_id[(s + 1) * kSkelStride + lane];
+                            sk_sc[s * kSkelStride + lane] = sk_sc[(s + 1) * kSkelStride + lane];
+                        }
+                    }
+                    nskel--;
+                }
+                __syncthreads();
+            } else if (num_found == 0) {  // :257-273
+                if (nskel < kMaxSkel) {
+                    if (lane < kSkelStride) {
+                        int idv = -1;
+                        float scv = -1.0f;
+                        if (lane == part1) { idv = id1; scv = c_score; }
+                        if (lane == part2) { idv = id2; scv = c_score; }
+                        if (lane == 19) { idv = 2; scv = c_len; }
+                        if (lane == 18) scv = __fadd_rn(__fadd_rn(ps1, ps2), c_score);
+                        sk_id[nskel * kSkelStride + lane] = idv;
+                        sk_sc[nskel * kSkelStride + lane] = scv;
+                    }
+                    nskel++;
+                } else {
+                    st |= PP_ST_SKEL_OVERFLOW;
+                }
+                __syncthreads();
+            }
+            // num_found > 2: no action
+        }
+    }
+
+    // ---- prune (:278-282) + records; order of survivors preserved
+    pp_record *rec = records + img;
+    int n_out = 0;
+    int n_conn_total = 0;
+    for (int l = lane; l < PP_NUM_LIMB; l += 64) n_conn_total += conn_counts[img * PP_NUM_LIMB + l];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) n_conn_total += __shfl_xor(n_conn_total, d);
+    for (int base = 0; base < nskel; base += 64) {
+        const int s = base + lane;
+        bool keep = false;
+        if (s < nskel) {
+            const int count = sk_id[s * kSkelStride + 19];
+            const float total = sk_sc[s * kSkelStride + 18];
+            keep = !(count < 2 || total / (float)count < 0.45f);
+        }
+        const unsigned long long m = __ballot(keep);
+        if (keep) {
+            const int r = n_out + __popcll(m & lanemask_lt());
+            if (r < PP_MAX_HUMANS) {
+                pp_human *hm = rec->humans + r;
+                const int count = sk_id[s * kSkelStride + 19];
+                for (int kp = 0; kp < PP_NUM_PART; kp++) {
+                    const int id = sk_id[s * kSkelStride + kp];
+                    hm->peak_id[kp] = id;
+                    const bool ok = id >= 0 && id < n_peaks;
+                    hm->x[kp] = ok ? line_x[id] : 0;
+                    hm->y[kp] = ok ? line_y[id] : 0;
+                    hm->part_score[kp] = ok ? line_s[id] : 0.0f;
+                }
+                hm->score = sk_sc[s * kSkelStride + 18] / (float)count;  // get_score, :295-297
+                hm->n_parts = count;
+            }
+        }
+        n_out += __popcll(m);
+    }
+    if (lane == 0) {
+        if (n_out > PP_MAX_HUMANS) {
+            st |= PP_ST_HUMAN_OVERFLOW;
+            n_out = PP_MAX_HUMANS;
+        }
+        rec->n_humans = n_out;
+        rec->n_peaks = n_peaks;
+        rec->n_connections = n_conn_total;
+        rec->status = status[img] | st;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+size_t lds_bytes_heat(int elem, int h, int w, int maxp) {
+    const size_t npix = (size_t)h * w, nchunks = (npix + 63) / 64;
+    return ((elem * npix + 15) & ~(size_t)15) + 64 + 8 * nchunks + 4 * (nchunks + 4) + 4 * (size_t)maxp;
+}
+size_t lds_bytes_limb(int elem, int h, int w, int maxp, int cap) {
+    const size_t npix = (size_t)h * w;
+    return ((elem * npix + 15) & ~(size_t)15) + 64 + 24 * (size_t)maxp + 8 + 20 * (size_t)cap;
+}
+size_t lds_bytes_limb_hwc(int maxp, int cap) { return 24 * (size_t)maxp + 8 + 20 * (size_t)cap; }
+size_t lds_bytes_assemble(int maxp) {
+    return (size_t)kMaxSkel * kSkelStride * 8 + (size_t)PP_NUM_PART * maxp * 16;
+}
+
+// Dynamic LDS above the 64 KB default needs the attribute; set once per process (pp_create), not per launch, so
+// that the per-batch entry points stay free of anything but kernel launches (hipGraph-capturable).
+hipError_t init_kernel_attributes() {
+    const int lim = (int)kMaxDynLds;
+    const void *fns[] = {reinterpret_cast<const void *>(&k_heat_peaks<__half>),
+                         reinterpret_cast<const void *>(&k_heat_peaks<float>),
+                         reinterpret_cast<const void *>(&k_limb_connect<__half>),
+                         reinterpret_cast<const void *>(&k_limb_connect<float>),
+                         reinterpret_cast<const void *>(&k_limb_connect_hwc),
+                         reinterpret_cast<const void *>(&k_assemble)};
+    for (const void *f : fns) {
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_heat_peaks(const void *net, int dtype, int batch, int n_samples, int h, int w, int flip, int refine,
+                             int nms_mode, float thr, int maxp, float4 *peaks, int *counts, unsigned *status,
+                             hipStream_t stream) {
+    const dim3 grid(PP_NUM_PART, batch), block(kThreads);
+    if (dtype == PP_F16) {
+        const size_t lds = lds_bytes_heat(2, h, w, maxp);
+        hipLaunchKernelGGL(k_heat_peaks<__half>, grid, block, lds, stream, static_cast<const __half *>(net), n_samples, h,
+                           w, flip, refine, nms_mode, thr, maxp, peaks, counts, status);
+    } else {
+        const size_t lds = lds_bytes_heat(4, h, w, maxp);
+        hipLaunchKernelGGL(k_heat_peaks<float>, grid, block, lds, stream, static_cast<const float *>(net), n_samples, h, w,
+                           flip, refine, nms_mode, thr, maxp, peaks, counts, status);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_limb_connect(const void *net, int dtype, int batch, int n_samples, int h, int w, int flip, int maxp,
+                               int cap, int min_img_size, const int *min_img_size_dev, const float4 *peaks,
+                               const int *counts, float4 *conns, int *conn_counts, unsigned *status,
+                               hipStream_t stream) {
+    const dim3 grid(PP_NUM_LIMB, batch), block(kThreads);
+    if (dtype == PP_F16) {
+        const size_t lds = lds_bytes_limb(2, h, w, maxp, cap);
+        hipLaunchKernelGGL(k_limb_connect<__half>, grid, block, lds, stream, static_cast<const __half *>(net), n_samples,
+                           h, w, flip, maxp, cap, min_img_size, min_img_size_dev, peaks, counts, conns, conn_counts,
+                           status);
+    } else {
+        const size_t lds = lds_bytes_limb(4, h, w, maxp, cap);
+        hipLaunchKernelGGL(k_limb_connect<float>, grid, block, lds, stream, static_cast<const float *>(net), n_samples, h,
+                           w, flip, maxp, cap, min_img_size, min_img_size_dev, peaks, counts, conns, conn_counts, status);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_limb_connect_hwc(const float *paf, int H, int W, int C, int maxp, int cap, int min_img_size,
+                                   const float4 *peaks, const int *counts, float4 *conns, int *conn_counts,
+                                   unsigned *status, hipStream_t stream) {
+    const size_t lds = lds_bytes_limb_hwc(maxp, cap);
+    hipLaunchKernelGGL(k_limb_connect_hwc, dim3(PP_NUM_LIMB), dim3(kThreads), lds, stream, paf, H, W, C, maxp, cap,
+                       min_img_size, peaks, counts, conns, conn_counts, status);
+    return hipGetLastError();
+}
+
+hipError_t launch_assemble(int batch, int maxp, int explicit_ids, const float4 *peaks, const int *counts,
+                           const float4 *conns, const int *conn_counts, unsigned *status, pp_record *records,
+                           hipStream_t stream) {
+    const size_t lds = lds_bytes_assemble(maxp);
+    hipLaunchKernelGGL(k_assemble, dim3(batch), dim3(64), lds, stream, maxp, explicit_ids, peaks, counts, conns,
+                       conn_counts, status, records);
+    return hipGetLastError();
+}
+
+}  // namespace pp

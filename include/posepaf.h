@@ -1,0 +1,151 @@
+/*
+ * posepaf.h -- C ABI of libposepaf.so: the MI355X (gfx950) post-processing path of the bottom-up pose
+ * pipeline (flip-average -> heat-map NMS/peak refinement -> limb-map line-integral scoring -> greedy
+ * limb matching -> person assembly), hand-written HIP behind plain pointers and sizes.
+ *
+ * Two groups of entry points:
+ *
+ *  (1) DROP-IN for the reference's native module `utils/pafprocess` -- the seven functions of
+ *      /root/reference/utils/pafprocess/pafprocess.h:70-76, same names, argument order and meaning,
+ *      exported with C linkage.  The SWIG interface (utils/pafprocess/pafprocess.i:14) or a ctypes stub
+ *      binds them unchanged; see INTEGRATION.md.  Host arrays in, results held until the next call.
+ *
+ *  (2) NATIVE batched path -- takes the network output where it already lives (HBM) and returns
+ *      fixed-size per-image records; this is what removes the reference's D2H copy
+ *      (utils/parse_skeletons.py:80), the per-peak cv2.resize loop (:143-163) and the 31.5 MB limb-map
+ *      upsample (evaluate.py:77-80).
+ *
+ * All functions return 0 (PP_OK) or a negative pp_status unless stated otherwise.  No function falls back
+ * to a CPU implementation: without a usable HIP device every compute entry point returns PP_ERR_NO_DEVICE.
+ */
+#ifndef POSEPAF_H
+#define POSEPAF_H
+
+#include <stdint.h>
+
+/* exported symbols (the library is built with -fvisibility=hidden) */
+#define PP_API __attribute__((visibility("default")))
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PP_NUM_PART 18    /* pafprocess.h:11  NUM_PART */
+#define PP_NUM_LIMB 30    /* pafprocess.h:20  COCOPAIRS_SIZE */
+#define PP_NUM_HEAT 20    /* utils/parse_skeletons.py:17 */
+#define PP_NUM_CH 50      /* config/config.py:127-129: [0,30) limb maps, [30,48) keypoints, [48,50) background */
+#define PP_MAX_HUMANS 128 /* capacity of one pp_record */
+#define PP_MAX_PEAKS_PER_PART_LIMIT 128
+
+typedef enum {
+    PP_OK = 0,
+    PP_ERR_NO_DEVICE = -1,   /* no HIP device / runtime error at create */
+    PP_ERR_BAD_ARG = -2,
+    PP_ERR_TOO_LARGE = -3,   /* batch/h/w beyond what the context was created for, or map does not fit LDS */
+    PP_ERR_HIP = -4,         /* a HIP call failed; pp_last_hip_error() has the code */
+    PP_ERR_OVERFLOW = -5     /* compat path only: a per-part / per-image capacity was exceeded */
+} pp_status;
+
+typedef enum { PP_F32 = 0, PP_F16 = 1 } pp_dtype;
+
+/* per-image status bits in pp_record.status */
+#define PP_ST_PEAK_OVERFLOW 1u   /* a keypoint channel had more peaks than max_peaks_per_part (extra dropped) */
+#define PP_ST_HUMAN_OVERFLOW 2u  /* more than PP_MAX_HUMANS people after pruning (extra dropped) */
+#define PP_ST_SKEL_OVERFLOW 4u   /* more live partial skeletons than the assembly table holds */
+#define PP_ST_SORT_UNDEFINED 8u  /* the reference's std::sort (non-strict comparator, pafprocess.cpp:333-335)
+                                    would have read outside its array on this input: its result is undefined */
+#define PP_ST_CAND_OVERFLOW 16u  /* more accepted limb candidates for one limb than the kernel holds */
+
+/* One person.  Mirrors what evaluate.py:111-127 pulls through the getters:
+ * peak_id[p] = get_part_peak_id(h,p) (-1 = part absent); x/y/part_score = get_part_x/y/score(peak_id);
+ * score = get_score(h) = total_score / part_count (pafprocess.cpp:295-297). */
+typedef struct {
+    int32_t peak_id[PP_NUM_PART];
+    int32_t x[PP_NUM_PART];
+    int32_t y[PP_NUM_PART];
+    float part_score[PP_NUM_PART];
+    float score;
+    int32_t n_parts;
+} pp_human;
+
+typedef struct {
+    int32_t n_humans;
+    int32_t n_peaks;
+    uint32_t status;
+    int32_t n_connections;
+    pp_human humans[PP_MAX_HUMANS];
+} pp_record;
+
+typedef struct pp_ctx pp_ctx;
+
+/* ---------------------------------------------------------------- context */
+
+/* Allocates all device workspace up front (no allocation or synchronisation happens in the per-batch
+ * calls, so they can be captured into a hipGraph).  max_h/max_w are FEATURE-map sizes (image/4).
+ * max_peaks_per_part in [1, 128]; 64 covers every synthetic scene up to 45 people. */
+PP_API int pp_create(pp_ctx **out, int device, int max_batch, int max_h, int max_w, int max_peaks_per_part);
+PP_API int pp_destroy(pp_ctx *ctx);
+PP_API int pp_last_hip_error(const pp_ctx *ctx);
+PP_API const char *pp_status_string(int status);
+/* 1 if a HIP device is visible to this process, 0 otherwise (does not create a context) */
+PP_API int pp_device_available(void);
+
+/* ---------------------------------------------------------------- native batched path
+ * net_out_dev: DEVICE pointer, (batch, n_samples, 50, h, w) planar, n_samples = 2 when flip (sample 1 is the
+ * network's output for the W-mirrored image, utils/parse_skeletons.py:69-72) else 1; dtype PP_F16 or PP_F32.
+ * With PP_F16 the flip-average is done in binary16 and then widened, exactly like numpy on the float16
+ * array of utils/parse_skeletons.py:91-93,103.
+ * min_img_size: the `img_h` argument of process_paf (evaluate.py:110), one value for the whole batch;
+ * min_img_size_dev (optional DEVICE int[batch]) overrides it per image.
+ * records_dev: DEVICE pp_record[batch].  stream: hipStream_t (NULL = default stream).  Asynchronous. */
+PP_API int pp_process_batch(pp_ctx *ctx, int batch, const void *net_out_dev, int dtype, int h, int w, int flip,
+                     int min_img_size, const int *min_img_size_dev, pp_record *records_dev, void *stream);
+
+/* Config-2 path: flip-average + NMS + refinement of the 18 keypoint channels only
+ * (utils/parse_skeletons.py:126-176).  peaks_dev: DEVICE float[batch][18][max_peaks_per_part][4] =
+ * (x, y, score, unused); counts_dev: DEVICE int[batch][18] (true counts, may exceed the capacity).
+ * refine = 0 reproduces bool_refine_center=False.  Either output may be NULL to use the context's own
+ * workspace (read back with pp_read_peaks). */
+PP_API int pp_nms_batch(pp_ctx *ctx, int batch, const void *net_out_dev, int dtype, int h, int w, int flip, int refine,
+                 float *peaks_dev, int *counts_dev, void *stream);
+
+/* Blocking read-backs of the context's workspace for the last batch (host pointers).
+ * pp_read_peaks: joint_list rows [x, y, score, peak_id, part] (evaluate.py:99-103) of one image. */
+PP_API int pp_read_peaks(pp_ctx *ctx, int image, float *joint_list_host, int max_rows, int *n_rows);
+/* connections of one limb of one image, rows {cid1, cid2, score, length} (pafprocess.h:60-67) */
+PP_API int pp_read_connections(pp_ctx *ctx, int image, int limb, float *rows_host, int max_rows, int *n_rows);
+/* device -> host copy of `batch` records, then synchronises the stream */
+PP_API int pp_read_records(pp_ctx *ctx, const pp_record *records_dev, pp_record *records_host, int batch, void *stream);
+
+/* ---------------------------------------------------------------- drop-in, context form
+ * Same contract as process_paf below but re-entrant: state lives in ctx. */
+PP_API int pp_process_paf_host(pp_ctx *ctx, int p1, int p2, int p3, const float *peaks, int f1, int f2, int f3,
+                        const float *pafmap, int min_img_size);
+PP_API int pp_get_num_humans(const pp_ctx *ctx);
+PP_API int pp_get_part_peak_id(const pp_ctx *ctx, int skeleton_id, int part_id);
+PP_API float pp_get_score(const pp_ctx *ctx, int skeleton_id);
+PP_API int pp_get_part_x(const pp_ctx *ctx, int cid);
+PP_API int pp_get_part_y(const pp_ctx *ctx, int cid);
+PP_API float pp_get_part_score(const pp_ctx *ctx, int cid);
+PP_API uint32_t pp_get_status(const pp_ctx *ctx);
+
+/* ---------------------------------------------------------------- drop-in, reference names
+ * Replaces /root/reference/utils/pafprocess/pafprocess.h:70-76 one for one.
+ *   peaks  : host float[p1][p2][p3], rows [x, y, score, peak_id, part]   (evaluate.py:99-107, p3 = 5)
+ *   pafmap : host float[f1][f2][f3] = (H, W, 30) up-sampled limb maps     (evaluate.py:77-80, :109)
+ * Results stay in one process-wide context until the next call (the reference keeps them in file-scope
+ * globals, pafprocess.cpp:16-17); like the reference this group is not re-entrant.
+ * process_paf returns 0 on success like the reference (pafprocess.cpp:284); unlike the reference it can
+ * fail, and then returns a negative pp_status (no device, capacity exceeded) instead of computing on the CPU. */
+PP_API int process_paf(int p1, int p2, int p3, float *peaks, int f1, int f2, int f3, float *pafmap, int min_img_size);
+PP_API int get_num_humans(void);
+PP_API int get_part_peak_id(int skeleton_id, int part_id);
+PP_API float get_score(int skeleton_id);
+PP_API int get_part_x(int cid);
+PP_API int get_part_y(int cid);
+PP_API float get_part_score(int cid);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POSEPAF_H */
