@@ -10,8 +10,12 @@ tests/test_constants.py asserts these against values captured from the imported 
 """
 import numpy as np
 
+# config/config.py:60-62 (the INI's part_str, utils/config:40, lists eyes/ears in the opposite order; the model
+# and the flip permutations follow config.py)
 PARTS = ["nose", "neck", "Rsho", "Relb", "Rwri", "Lsho", "Lelb", "Lwri", "Rhip", "Rkne", "Rank",
-         "Lhip", "Lkne", "Lank", "Leye", "Reye", "Lear", "Rear"]
+         "Lhip", "Lkne", "Lank", "Reye", "Leye", "Rear", "Lear"]
+PART_STR_INI = ["nose", "neck", "Rsho", "Relb", "Rwri", "Lsho", "Lelb", "Lwri", "Rhip", "Rkne", "Rank",
+                "Lhip", "Lkne", "Lank", "Leye", "Reye", "Lear", "Rear", "pt19"]
 NUM_PART = 18
 NUM_LIMB = 30
 NUM_HEAT = NUM_PART + 2          # 18 keypoint maps + 2 background maps
@@ -61,4 +65,4 @@ def default_test_cfg():
 def default_model_cfg():
     """`model` dict of utils/config_reader.py (utils/config [[1]] section), typed."""
     return {"boxsize": BOXSIZE, "padValue": PAD_VALUE, "np": "12", "stride": STRIDE,
-            "max_downsample": MAX_DOWNSAMPLE, "part_str": PARTS + ["pt19"]}
+            "max_downsample": MAX_DOWNSAMPLE, "part_str": list(PART_STR_INI)}

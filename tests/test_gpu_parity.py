@@ -112,8 +112,9 @@ def test_no_flip_and_empty_and_single_peak(torch_cuda, post, oracle):
     z = np.zeros((1, 2, 50, 128, 128), np.float16)
     rec = post.process(torch.from_numpy(z).cuda(), 512)[0]
     assert rec["n_humans"] == 0 and rec["n_peaks"] == 0 and rec["n_connections"] == 0
-    # one isolated keypoint: peaks but no limbs
-    z[0, :, 30, 60, 60] = 0.9
+    # one isolated keypoint (and its mirror image in the flipped sample): peaks but no limbs
+    z[0, 0, 30, 60, 60] = 0.9
+    z[0, 1, 30, 60, 127 - 60] = 0.9
     rec = post.process(torch.from_numpy(z).cuda(), 512)[0]
     assert rec["n_peaks"] == 1 and rec["n_humans"] == 0
     jl = post.read_peaks(0)
