@@ -176,6 +176,44 @@ int pp_process_batch(pp_ctx *ctx, int batch, const void *net_out_dev, int dtype,
     return PP_OK;
 }
 
+int pp_time_kernels(pp_ctx *ctx, int batch, const void *net_out_dev, int dtype, int h, int w, int flip,
+                    int min_img_size, int iters, float *ms_out, void *stream) {
+    int rc = check_shape(ctx, batch, dtype, h, w);
+    if (rc != PP_OK) return rc;
+    if (!net_out_dev || !ms_out || iters <= 0) return PP_ERR_BAD_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int ns = flip ? 2 : 1;
+    hipEvent_t e0, e1;
+    PP_HIP(ctx, hipEventCreate(&e0));
+    PP_HIP(ctx, hipEventCreate(&e1));
+    // one untimed pass so that every kernel's inputs exist
+    rc = pp_process_batch(ctx, batch, net_out_dev, dtype, h, w, flip, min_img_size, nullptr, nullptr, st);
+    if (rc != PP_OK) return rc;
+    for (int k = 0; k < 3; k++) {
+        PP_HIP(ctx, hipEventRecord(e0, st));
+        for (int i = 0; i < iters; i++) {
+            if (k == 0)
+                PP_HIP(ctx, pp::launch_heat_peaks(net_out_dev, dtype, batch, ns, h, w, flip, 1, 0, 0.1f, ctx->maxp,
+                                                  ctx->d_peaks, ctx->d_counts, ctx->d_status, st));
+            else if (k == 1)
+                PP_HIP(ctx, pp::launch_limb_connect(net_out_dev, dtype, batch, ns, h, w, flip, ctx->maxp, ctx->cap,
+                                                    min_img_size, nullptr, ctx->d_peaks, ctx->d_counts, ctx->d_conns,
+                                                    ctx->d_conn_counts, ctx->d_status, st));
+            else
+                PP_HIP(ctx, pp::launch_assemble(batch, ctx->maxp, 0, ctx->d_peaks, ctx->d_counts, ctx->d_conns,
+                                                ctx->d_conn_counts, ctx->d_status, ctx->d_records, st));
+        }
+        PP_HIP(ctx, hipEventRecord(e1, st));
+        PP_HIP(ctx, hipEventSynchronize(e1));
+        float ms = 0.f;
+        PP_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+        ms_out[k] = ms / (float)iters;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return PP_OK;
+}
+
 int pp_read_peaks(pp_ctx *ctx, int image, float *joint_list_host, int max_rows, int *n_rows) {
     if (!ctx || !n_rows || image < 0 || image >= ctx->last_batch || !ctx->last_peaks) return PP_ERR_BAD_ARG;
     PP_HIP(ctx, hipStreamSynchronize(ctx->last_stream));

@@ -82,6 +82,16 @@ class PosePostProcessor:
                                        int(flip), int(refine), None, None, C.c_void_p(stream)), self.ctx)
         return [self.read_peaks(i) for i in range(B)]
 
+    def time_kernels(self, net_out, min_img_size: int = 512, flip: bool = True, iters: int = 20):
+        """HIP-event timing of each kernel on torch's current stream: dict name -> ms per launch."""
+        import torch
+        B, h, w = self._check_input(net_out, flip)
+        ms = (C.c_float * 3)()
+        stream = torch.cuda.current_stream(net_out.device).cuda_stream
+        _lib.check(self.L.pp_time_kernels(self.ctx, B, C.c_void_p(net_out.data_ptr()), self._dtype_code(net_out), h, w,
+                                          int(flip), int(min_img_size), int(iters), ms, C.c_void_p(stream)), self.ctx)
+        return {"k_heat_peaks": ms[0], "k_limb_connect": ms[1], "k_assemble": ms[2]}
+
     def read_peaks(self, image: int) -> np.ndarray:
         cap = _lib.NUM_PART * self.maxp
         buf = np.empty((cap, 5), np.float32)

@@ -1,0 +1,191 @@
+"""Inference-time form of the IMHN for MI355X: BatchNorm folded into the convolutions, fp16, channels-last
+(NHWC is also the layout the images arrive in, utils/parse_skeletons.py:60-73, so the input permute is free),
+dead heads removed, whole forward replayed from a HIP graph.
+
+The convolutions run on PyTorch-ROCm (MIOpen); what this module adds is structural:
+  * BN (eval) folded:  w' = w * g / sqrt(var + eps),  b' = beta - mean * g / sqrt(var + eps)
+  * only `[-1][0]` (last stage, full-resolution scale) is produced -- the sole output the inference path reads
+    (utils/parse_skeletons.py:80); the last stage's coarse-scale feature/pred heads feed nothing and are skipped
+  * LeakyReLU applied in place on the conv output
+
+`FusedIMHN.from_network(NetworkEval)` takes the weights of the checkpoint-compatible definition in
+models/posenet.py, so a reference checkpoint loads there (strict=True) and is then folded here.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+LEAK = 0.01
+
+
+def _fold(conv: nn.Conv2d, bn: nn.BatchNorm2d | None):
+    w = conv.weight.detach().float()
+    b = conv.bias.detach().float() if conv.bias is not None else torch.zeros(w.shape[0], device=w.device)
+    if bn is not None:
+        s = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+        w = w * s.view(-1, 1, 1, 1)
+        b = (b - bn.running_mean.detach().float()) * s + bn.bias.detach().float()
+    return w, b
+
+
+class FConv(nn.Module):
+    """conv + folded-BN bias [+ LeakyReLU]"""
+
+    def __init__(self, conv: nn.Conv2d, bn, act: bool):
+        super().__init__()
+        w, b = _fold(conv, bn)
+        self.weight = nn.Parameter(w, requires_grad=False)
+        self.bias = nn.Parameter(b, requires_grad=False)
+        self.stride, self.padding, self.dilation = conv.stride, conv.padding, conv.dilation
+        self.act = act
+
+    def forward(self, x):
+        y = F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation)
+        return F.leaky_relu_(y, LEAK) if self.act else y
+
+
+def _fconv_from_block(m, act=None):  # models.layers_transposed.Conv / DilatedConv
+    return FConv(m.conv, m.bn, m.relu is not None if act is None else act)
+
+
+class FResidual(nn.Module):
+    def __init__(self, r):
+        super().__init__()
+        cb = r.convBlock
+        self.c1 = FConv(cb[0], cb[1], True)
+        self.c2 = FConv(cb[3], cb[4], True)
+        self.c3 = FConv(cb[6], cb[7], False)
+        self.skip = FConv(r.skipConv[0], r.skipConv[1], False) if r.ins != r.outs else None
+        self.act = r.relu_flag
+
+    def forward(self, x):
+        y = self.c3(self.c2(self.c1(x)))
+        y += self.skip(x) if self.skip is not None else x
+        return F.leaky_relu_(y, LEAK) if self.act else y
+
+
+class FHourglass(nn.Module):
+    def __init__(self, hg):
+        super().__init__()
+        self.depth = hg.depth
+        self.levels = nn.ModuleList()
+        for i in range(hg.depth):
+            mods = [FResidual(hg.hg[i][0]), FResidual(hg.hg[i][1]), FResidual(hg.hg[i][2]), _fconv_from_block(hg.hg[i][3])]
+            if i == hg.depth - 1:
+                mods.append(FResidual(hg.hg[i][4]))
+            self.levels.append(nn.ModuleList(mods))
+
+    def _level(self, i, x, coarse):
+        lv = self.levels[i]
+        up1 = lv[0](x)
+        low = lv[1](F.max_pool2d(x, 2, 2))
+        low = lv[4](low) if i == self.depth - 1 else self._level(i + 1, low, coarse)
+        coarse.append(low)
+        up2 = F.interpolate(lv[2](low), scale_factor=2, mode="nearest")
+        return up1 + lv[3](up2)
+
+    def forward(self, x):
+        coarse = []
+        top = self._level(0, x, coarse)
+        return [top] + coarse[::-1]
+
+
+class FSE(nn.Module):
+    def __init__(self, se):
+        super().__init__()
+        self.fc1, self.fc2 = se.fc[0], se.fc[2]
+
+    def forward(self, x):
+        y = x.mean(dim=(2, 3))
+        y = torch.sigmoid(self.fc2(F.leaky_relu(self.fc1(y), 0.01)))
+        return x * y[:, :, None, None]
+
+
+class FFeature(nn.Module):
+    def __init__(self, seq):
+        super().__init__()
+        self.c1, self.c2, self.se = _fconv_from_block(seq[0]), _fconv_from_block(seq[1]), FSE(seq[2])
+
+    def forward(self, x):
+        return self.se(self.c2(self.c1(x)))
+
+
+class FusedIMHN(nn.Module):
+    """forward(NHWC image batch in [0,1]) -> (N, 50, H/4, W/4): the `[-1][0]` output of NetworkEval."""
+
+    def __init__(self, net):
+        super().__init__()
+        p = net.posenet
+        self.S, self.K = p.num_stages, p.num_scales
+        pre = p.pre
+        self.stem = FConv(pre.conv1, pre.bn1, True)
+        self.res1, self.res2 = FResidual(pre.res1), FResidual(pre.res2)
+        self.dil = nn.ModuleList([_fconv_from_block(d) for d in pre.dilation])
+        self.hg = nn.ModuleList([FHourglass(h) for h in p.hourglass])
+        self.feat = nn.ModuleList([nn.ModuleList([FFeature(s) for s in f.before_regress]) for f in p.features])
+        self.head = nn.ModuleList([nn.ModuleList([_fconv_from_block(c) for c in o]) for o in p.outs])
+        self.mfeat = nn.ModuleList([nn.ModuleList([_fconv_from_block(m.conv) for m in ms]) for ms in p.merge_features])
+        self.mpred = nn.ModuleList([nn.ModuleList([_fconv_from_block(m.conv) for m in ms]) for ms in p.merge_preds])
+
+    @classmethod
+    def from_network(cls, net):
+        return cls(net)
+
+    def forward(self, imgs):
+        x = imgs.permute(0, 3, 1, 2)  # NHWC storage viewed as NCHW == channels_last: no copy
+        x = self.stem(x)
+        x = self.res2(F.max_pool2d(self.res1(x), 2, 2))
+        d = x
+        for m in self.dil:
+            d = m(d)
+        x = torch.cat([x, d], dim=1)
+        caches = None
+        for t in range(self.S):
+            hg = self.hg[t](x)
+            if caches is not None:
+                hg = [a + c for a, c in zip(hg, caches)]
+            last = t == self.S - 1
+            scales = range(1) if last else range(self.K)  # the last stage's coarse heads feed nothing
+            feats = [self.feat[t][s](hg[s]) for s in scales]
+            preds = [self.head[t][s](feats[s]) for s in scales]
+            if last:
+                return preds[0]
+            caches = [self.mpred[t][s](preds[s]) + self.mfeat[t][s](feats[s]) for s in scales]
+            x = x + caches[0]
+
+
+class GraphedForward:
+    """Replays module(x) from a HIP graph for a fixed input shape (launch-bound coarse levels: ~900 kernels)."""
+
+    def __init__(self, module, example: torch.Tensor, warmup: int = 3):
+        self.module = module
+        self.static_in = example.clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s), torch.no_grad():
+            for _ in range(warmup):
+                self.module(self.static_in)
+        torch.cuda.current_stream().wait_stream(s)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            self.static_out = self.module(self.static_in)
+
+    def __call__(self, x):
+        self.static_in.copy_(x)
+        self.graph.replay()
+        return self.static_out
+
+
+def build_inference_model(device, fused: bool = True, seed: int = 7, dtype=torch.float16):
+    """Random-init (deterministic, name-seeded) IMHN ready for inference on `device`."""
+    from config.config import GetConfig, TrainingOpt
+    from models.posenet import NetworkEval
+    from .model_init import deterministic_init
+    net = NetworkEval(TrainingOpt(), GetConfig("Canonical"), bn=True).eval()
+    deterministic_init(net, seed)
+    if not fused:
+        return net.to(device=device, dtype=dtype).to(memory_format=torch.channels_last)
+    m = FusedIMHN.from_network(net).eval()
+    return m.to(device=device, dtype=dtype).to(memory_format=torch.channels_last)

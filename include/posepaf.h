@@ -109,6 +109,12 @@ PP_API int pp_process_batch(pp_ctx *ctx, int batch, const void *net_out_dev, int
 PP_API int pp_nms_batch(pp_ctx *ctx, int batch, const void *net_out_dev, int dtype, int h, int w, int flip, int refine,
                  float *peaks_dev, int *counts_dev, void *stream);
 
+/* Measurement aid: runs the three kernels of pp_process_batch `iters` times EACH on `stream`, bracketed by HIP
+ * events on that stream, and returns the average duration of one launch in milliseconds:
+ * ms_out[0] = k_heat_peaks, ms_out[1] = k_limb_connect, ms_out[2] = k_assemble.  Blocking. */
+PP_API int pp_time_kernels(pp_ctx *ctx, int batch, const void *net_out_dev, int dtype, int h, int w, int flip,
+                           int min_img_size, int iters, float *ms_out, void *stream);
+
 /* Blocking read-backs of the context's workspace for the last batch (host pointers).
  * pp_read_peaks: joint_list rows [x, y, score, peak_id, part] (evaluate.py:99-103) of one image. */
 PP_API int pp_read_peaks(pp_ctx *ctx, int image, float *joint_list_host, int max_rows, int *n_rows);
