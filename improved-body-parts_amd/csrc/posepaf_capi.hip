@@ -107,7 +107,7 @@ int pp_create(pp_ctx **out, int device, int max_batch, int max_h, int max_w, int
     c->max_h = max_h;
     c->max_w = max_w;
     c->maxp = max_peaks_per_part;
-    c->cap = max_peaks_per_part * max_peaks_per_part < 1024 ? max_peaks_per_part * max_peaks_per_part : 1024;
+    c->cap = max_peaks_per_part * max_peaks_per_part < 512 ? max_peaks_per_part * max_peaks_per_part : 512;
     hipError_t e = pp::init_kernel_attributes();
     const size_t B = (size_t)max_batch;
     if (e == hipSuccess) e = hipMalloc(&c->d_peaks, B * PP_NUM_PART * c->maxp * sizeof(float4));

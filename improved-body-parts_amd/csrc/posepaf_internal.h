@@ -8,8 +8,8 @@
 
 namespace pp {
 
-// 160 KiB of LDS per CU (gfx950) minus room for the kernels' few static __shared__ words
-constexpr size_t kMaxDynLds = 163840 - 1024;
+// 160 KiB of LDS per CU (gfx950) minus room for the kernels' static __shared__ arrays (< 2 KB)
+constexpr size_t kMaxDynLds = 163840 - 4096;
 hipError_t init_kernel_attributes();
 
 size_t lds_bytes_heat(int elem, int h, int w, int maxp);

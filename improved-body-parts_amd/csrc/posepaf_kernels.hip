@@ -67,6 +67,10 @@ __device__ __forceinline__ __half2 avg_h2(__half2 a, __half2 b) {
 }
 __device__ __forceinline__ __half2 swap_h2(__half2 v) { return __lowhigh2highlow(v); }
 
+// Each thread issues kLoadUnroll 16-byte loads per operand before touching any of them (2*kLoadUnroll loads in
+// flight per lane) -- the loop is latency-bound otherwise.
+constexpr int kLoadUnroll = 4;
+
 __device__ void load_channel(__half *smap, const __half *o0, const __half *o1, int h, int w, bool flip) {
     const int npix = h * w;
     const bool vec_ok = (w % 8 == 0) && ((reinterpret_cast<uintptr_t>(o0) & 15) == 0) &&
@@ -74,20 +78,37 @@ __device__ void load_channel(__half *smap, const __half *o0, const __half *o1, i
     if (vec_ok) {
         const int nvec = npix / 8;
         const int vpr = w / 8;  // vectors per row
-        for (int v = threadIdx.x; v < nvec; v += kThreads) {
-            uint4 a = reinterpret_cast<const uint4 *>(o0)[v];
-            if (flip) {
-                const int y = v / vpr, vx = v - y * vpr;
-                uint4 m = reinterpret_cast<const uint4 *>(o1)[y * vpr + (vpr - 1 - vx)];
-                __half2 *ah = reinterpret_cast<__half2 *>(&a);
-                const __half2 *mh = reinterpret_cast<const __half2 *>(&m);
-                // reversed 8-vector: element j pairs with mirrored element 7-j
-                ah[0] = avg_h2(ah[0], swap_h2(mh[3]));
-                ah[1] = avg_h2(ah[1], swap_h2(mh[2]));
-                ah[2] = avg_h2(ah[2], swap_h2(mh[1]));
-                ah[3] = avg_h2(ah[3], swap_h2(mh[0]));
+        const uint4 *p0 = reinterpret_cast<const uint4 *>(o0);
+        const uint4 *p1 = reinterpret_cast<const uint4 *>(o1);
+        for (int v0 = threadIdx.x; v0 < nvec; v0 += kThreads * kLoadUnroll) {
+            uint4 a[kLoadUnroll], m[kLoadUnroll];
+#pragma unroll
+            for (int u = 0; u < kLoadUnroll; u++) {
+                const int v = v0 + u * kThreads;
+                if (v < nvec) {
+                    a[u] = p0[v];
+                    if (flip) {
+                        const int y = v / vpr, vx = v - y * vpr;
+                        m[u] = p1[y * vpr + (vpr - 1 - vx)];
+                    }
+                }
             }
-            reinterpret_cast<uint4 *>(smap)[v] = a;
+#pragma unroll
+            for (int u = 0; u < kLoadUnroll; u++) {
+                const int v = v0 + u * kThreads;
+                if (v < nvec) {
+                    if (flip) {
+                        __half2 *ah = reinterpret_cast<__half2 *>(&a[u]);
+                        const __half2 *mh = reinterpret_cast<const __half2 *>(&m[u]);
+                        // reversed 8-vector: element j pairs with mirrored element 7-j
+                        ah[0] = avg_h2(ah[0], swap_h2(mh[3]));
+                        ah[1] = avg_h2(ah[1], swap_h2(mh[2]));
+                        ah[2] = avg_h2(ah[2], swap_h2(mh[1]));
+                        ah[3] = avg_h2(ah[3], swap_h2(mh[0]));
+                    }
+                    reinterpret_cast<uint4 *>(smap)[v] = a[u];
+                }
+            }
         }
     } else {
         for (int i = threadIdx.x; i < npix; i += kThreads) {
@@ -108,17 +129,34 @@ __device__ void load_channel(float *smap, const float *o0, const float *o1, int 
     if (vec_ok) {
         const int nvec = npix / 4;
         const int vpr = w / 4;
-        for (int v = threadIdx.x; v < nvec; v += kThreads) {
-            float4 a = reinterpret_cast<const float4 *>(o0)[v];
-            if (flip) {
-                const int y = v / vpr, vx = v - y * vpr;
-                const float4 m = reinterpret_cast<const float4 *>(o1)[y * vpr + (vpr - 1 - vx)];
-                a.x = __fadd_rn(a.x, m.w) / 2.0f;
-                a.y = __fadd_rn(a.y, m.z) / 2.0f;
-                a.z = __fadd_rn(a.z, m.y) / 2.0f;
-                a.w = __fadd_rn(a.w, m.x) / 2.0f;
+        const float4 *p0 = reinterpret_cast<const float4 *>(o0);
+        const float4 *p1 = reinterpret_cast<const float4 *>(o1);
+        for (int v0 = threadIdx.x; v0 < nvec; v0 += kThreads * kLoadUnroll) {
+            float4 a[kLoadUnroll], m[kLoadUnroll];
+#pragma unroll
+            for (int u = 0; u < kLoadUnroll; u++) {
+                const int v = v0 + u * kThreads;
+                if (v < nvec) {
+                    a[u] = p0[v];
+                    if (flip) {
+                        const int y = v / vpr, vx = v - y * vpr;
+                        m[u] = p1[y * vpr + (vpr - 1 - vx)];
+                    }
+                }
             }
-            reinterpret_cast<float4 *>(smap)[v] = a;
+#pragma unroll
+            for (int u = 0; u < kLoadUnroll; u++) {
+                const int v = v0 + u * kThreads;
+                if (v < nvec) {
+                    if (flip) {
+                        a[u].x = __fadd_rn(a[u].x, m[u].w) / 2.0f;
+                        a[u].y = __fadd_rn(a[u].y, m[u].z) / 2.0f;
+                        a[u].z = __fadd_rn(a[u].z, m[u].y) / 2.0f;
+                        a[u].w = __fadd_rn(a[u].w, m[u].x) / 2.0f;
+                    }
+                    reinterpret_cast<float4 *>(smap)[v] = a[u];
+                }
+            }
         }
     } else {
         for (int i = threadIdx.x; i < npix; i += kThreads) {
@@ -185,6 +223,7 @@ __global__ __launch_bounds__(kThreads) void k_heat_peaks(const T *__restrict__ n
     int *s_pk = reinterpret_cast<int *>(lds_raw + off);
     __shared__ int s_wsum[kWaves];
     __shared__ int s_total;
+    __shared__ float s_hpass[kWaves][5 * 20];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x < 16) s_cub[threadIdx.x] = d_cubic4[threadIdx.x >> 2][threadIdx.x & 3];
@@ -196,29 +235,39 @@ __global__ __launch_bounds__(kThreads) void k_heat_peaks(const T *__restrict__ n
     __syncthreads();
 
     // ---- A3: local maxima, 64 consecutive row-major pixels per wave step, one ballot each
-    for (int chunk = wave; chunk < nchunks; chunk += kWaves) {
-        const int i = (chunk << 6) + lane;
-        bool pk = false;
-        if (i < npix) {
-            const float v = ldsf(smap, i);
-            const bool above = nms_mode == 0 ? (v > thr) : (v >= thr);  // parse_skeletons.py:116 / util.py:184
-            if (above) {
-                const int y = i / w, x = i - y * w;
-                pk = true;
-                if (y > 0 && ldsf(smap, i - w) > v) pk = false;
-                if (y < h - 1 && ldsf(smap, i + w) > v) pk = false;
-                if (x > 0 && ldsf(smap, i - 1) > v) pk = false;
-                if (x < w - 1 && ldsf(smap, i + 1) > v) pk = false;
-                if (nms_mode != 0) {  // full 3x3 window (utils/util.py:181-184)
-                    if (y > 0 && x > 0 && ldsf(smap, i - w - 1) > v) pk = false;
-                    if (y > 0 && x < w - 1 && ldsf(smap, i - w + 1) > v) pk = false;
-                    if (y < h - 1 && x > 0 && ldsf(smap, i + w - 1) > v) pk = false;
-                    if (y < h - 1 && x < w - 1 && ldsf(smap, i + w + 1) > v) pk = false;
+    {
+        const int step = kWaves * 64;
+        const int dy = step / w, dx = step - dy * w;
+        int i = (wave << 6) + lane;
+        int y = i / w, x = i - y * w;
+        for (int chunk = wave; chunk < nchunks; chunk += kWaves, i += step) {
+            bool pk = false;
+            if (i < npix) {
+                const float v = ldsf(smap, i);
+                const bool above = nms_mode == 0 ? (v > thr) : (v >= thr);  // parse_skeletons.py:116 / util.py:184
+                if (above) {
+                    pk = true;
+                    if (y > 0 && ldsf(smap, i - w) > v) pk = false;
+                    if (y < h - 1 && ldsf(smap, i + w) > v) pk = false;
+                    if (x > 0 && ldsf(smap, i - 1) > v) pk = false;
+                    if (x < w - 1 && ldsf(smap, i + 1) > v) pk = false;
+                    if (nms_mode != 0) {  // full 3x3 window (utils/util.py:181-184)
+                        if (y > 0 && x > 0 && ldsf(smap, i - w - 1) > v) pk = false;
+                        if (y > 0 && x < w - 1 && ldsf(smap, i - w + 1) > v) pk = false;
+                        if (y < h - 1 && x > 0 && ldsf(smap, i + w - 1) > v) pk = false;
+                        if (y < h - 1 && x < w - 1 && ldsf(smap, i + w + 1) > v) pk = false;
+                    }
                 }
             }
+            const unsigned long long m = __ballot(pk);
+            if (lane == 0) s_mask[chunk] = m;
+            x += dx;
+            y += dy;
+            if (x >= w) {
+                x -= w;
+                y += 1;
+            }
         }
-        const unsigned long long m = __ballot(pk);
-        if (lane == 0) s_mask[chunk] = m;
     }
     __syncthreads();
 
@@ -268,16 +317,39 @@ __global__ __launch_bounds__(kThreads) void k_heat_peaks(const T *__restrict__ n
             const int x_max = px + 2 > w - 1 ? w - 1 : px + 2, y_max = py + 2 > h - 1 ? h - 1 : py + 2;
             const int pw = x_max - x_min + 1, ph = y_max - y_min + 1;
             const int uw = pw * 4, n = uw * ph * 4;
+            // separable evaluation, same arithmetic as the per-pixel form: the horizontal pass of every patch row
+            // is computed once (ph x uw values, kept in this wave's LDS scratch), the vertical pass reads 4 of them
+            float *hp = s_hpass[wave];
+            for (int k = lane; k < ph * uw; k += 64) {
+                const int j = k / uw, col = k - j * uw;
+                const int sx = ((col + 2) >> 2) - 1;
+                const float4 ca = reinterpret_cast<const float4 *>(s_cub)[col & 3];
+                const T *row = smap + (y_min + j) * w + x_min;
+                float v = __fmul_rn(ldsf(row, clampi(sx - 1, 0, pw - 1)), ca.x);
+                v = __fadd_rn(v, __fmul_rn(ldsf(row, clampi(sx, 0, pw - 1)), ca.y));
+                v = __fadd_rn(v, __fmul_rn(ldsf(row, clampi(sx + 1, 0, pw - 1)), ca.z));
+                v = __fadd_rn(v, __fmul_rn(ldsf(row, clampi(sx + 2, 0, pw - 1)), ca.w));
+                hp[k] = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // this wave's LDS writes precede its reads below
+            __builtin_amdgcn_wave_barrier();
             float best_v = -INFINITY;
             int best_k = 0x7fffffff;
             for (int k = lane; k < n; k += 64) {
                 const int row = k / uw, col = k - row * uw;
-                const float v = bicubic4_at(smap, w, x_min, y_min, pw, ph, col, row, s_cub);
+                const int sy = ((row + 2) >> 2) - 1;
+                const float4 cb = reinterpret_cast<const float4 *>(s_cub)[row & 3];
+                float v = __fmul_rn(hp[clampi(sy - 1, 0, ph - 1) * uw + col], cb.x);
+                v = __fadd_rn(v, __fmul_rn(hp[clampi(sy, 0, ph - 1) * uw + col], cb.y));
+                v = __fadd_rn(v, __fmul_rn(hp[clampi(sy + 1, 0, ph - 1) * uw + col], cb.z));
+                v = __fadd_rn(v, __fmul_rn(hp[clampi(sy + 2, 0, ph - 1) * uw + col], cb.w));
                 if (v > best_v || best_k == 0x7fffffff) {
                     best_v = v;
                     best_k = k;
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
             // arg-max with first-occurrence tie-break (ndarray.argmax, :156)
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) {
@@ -328,50 +400,59 @@ struct GlobalHwcSampler {  // drop-in path: caller supplies the already up-sampl
     }
 };
 
+constexpr int kSortStack = 48;
+
+// libstdc++ std::sort (introsort, threshold 16, depth limit 2*floor(log2 n), heapsort fallback, final
+// insertion sort) with the reference's comparator a.overall_score >= b.overall_score
+// (pafprocess.cpp:109, :333-335), executed by ONE lane on LDS arrays (key[i], gen[i]).  Tied keys are common on
+// this path (duplicate peaks) and the order among ties decides the greedy matching, so the algorithm itself is
+// part of the result; it is restated step for step (see oracle/posepaf_oracle.c for the same restatement in C).
+// It only runs when a limb has MORE than 16 accepted candidates AND at least one exact tie -- otherwise the
+// sorted order is unique, or (n <= 16: pure insertion sort) has a closed form, and ranks are computed in parallel.
+// Scans that libstdc++ leaves unguarded stop at the array bounds here and set oob.
 struct SortElem {
     float key;
     int gen;
 };
-
-// libstdc++ std::sort (introsort, threshold 16, depth limit 2*floor(log2 n), heapsort fallback, final
-// insertion sort) with the reference's comparator a.overall_score >= b.overall_score
-// (pafprocess.cpp:109, :333-335), executed by ONE lane on an LDS array.  Tied keys are common on this path
-// (duplicate peaks) and the order among ties decides the greedy matching, so the algorithm itself is part of
-// the result; it is restated step for step (see oracle/posepaf_oracle.c for the same restatement in C).
-// Scans that libstdc++ leaves unguarded stop at the array bounds here and set *oob.
 struct StdSortGE {
-    SortElem *b;
+    float *key;
+    int *gen;
     int n;
     bool oob;
     __device__ __forceinline__ static bool ge(const SortElem &a, const SortElem &c) { return a.key >= c.key; }
+    __device__ __forceinline__ SortElem get(int i) const { return SortElem{key[i], gen[i]}; }
+    __device__ __forceinline__ void put(int i, const SortElem &e) {
+        key[i] = e.key;
+        gen[i] = e.gen;
+    }
     __device__ __forceinline__ void swp(int i, int j) {
-        const SortElem t = b[i];
-        b[i] = b[j];
-        b[j] = t;
+        const SortElem t = get(i);
+        put(i, get(j));
+        put(j, t);
     }
     __device__ void unguarded_linear_insert(int last) {
-        const SortElem val = b[last];
+        const SortElem val = get(last);
         int next = last - 1;
         while (true) {
             if (next < 0) {
                 oob = true;
                 break;
             }
-            const SortElem nx = b[next];
+            const SortElem nx = get(next);
             if (!ge(val, nx)) break;
-            b[last] = nx;
+            put(last, nx);
             last = next;
             --next;
         }
-        b[last] = val;
+        put(last, val);
     }
     __device__ void insertion_sort(int first, int last) {
         if (first == last) return;
         for (int i = first + 1; i != last; ++i) {
-            const SortElem val = b[i];
-            if (ge(val, b[first])) {
-                for (int k = i; k > first; --k) b[k] = b[k - 1];
-                b[first] = val;
+            const SortElem val = get(i);
+            if (ge(val, get(first))) {
+                for (int k = i; k > first; --k) put(k, get(k - 1));
+                put(first, val);
             } else {
                 unguarded_linear_insert(i);
             }
@@ -379,25 +460,25 @@ struct StdSortGE {
     }
     __device__ void push_heap(int first, int hole, int top, SortElem value) {
         int parent = (hole - 1) / 2;
-        while (hole > top && ge(b[first + parent], value)) {
-            b[first + hole] = b[first + parent];
+        while (hole > top && ge(get(first + parent), value)) {
+            put(first + hole, get(first + parent));
             hole = parent;
             parent = (hole - 1) / 2;
         }
-        b[first + hole] = value;
+        put(first + hole, value);
     }
     __device__ void adjust_heap(int first, int hole, int len, SortElem value) {
         const int top = hole;
         int child = hole;
         while (child < (len - 1) / 2) {
             child = 2 * (child + 1);
-            if (ge(b[first + child], b[first + child - 1])) child--;
-            b[first + hole] = b[first + child];
+            if (ge(get(first + child), get(first + child - 1))) child--;
+            put(first + hole, get(first + child));
             hole = child;
         }
         if ((len & 1) == 0 && child == (len - 2) / 2) {
             child = 2 * (child + 1);
-            b[first + hole] = b[first + child - 1];
+            put(first + hole, get(first + child - 1));
             hole = child - 1;
         }
         push_heap(first, hole, top, value);
@@ -407,20 +488,20 @@ struct StdSortGE {
         if (len >= 2) {
             int parent = (len - 2) / 2;
             while (true) {
-                adjust_heap(first, parent, len, b[first + parent]);
+                adjust_heap(first, parent, len, get(first + parent));
                 if (parent == 0) break;
                 parent--;
             }
         }
         while (last - first > 1) {
             --last;
-            const SortElem v = b[last];
-            b[last] = b[first];
+            const SortElem v = get(last);
+            put(last, get(first));
             adjust_heap(first, 0, last - first, v);
         }
     }
     __device__ void move_median_to_first(int result, int a, int m, int c) {
-        const SortElem va = b[a], vm = b[m], vc = b[c];
+        const SortElem va = get(a), vm = get(m), vc = get(c);
         if (ge(va, vm)) {
             if (ge(vm, vc)) swp(result, m);
             else if (ge(va, vc)) swp(result, c);
@@ -430,14 +511,14 @@ struct StdSortGE {
         else swp(result, m);
     }
     __device__ int unguarded_partition(int first, int last, int pivot) {
-        const SortElem pv = b[pivot];  // the pivot slot is never written during the partition
+        const SortElem pv = get(pivot);  // the pivot slot is never written during the partition
         while (true) {
             while (true) {
                 if (first >= n) {
                     oob = true;
                     break;
                 }
-                if (!ge(b[first], pv)) break;
+                if (!ge(get(first), pv)) break;
                 ++first;
             }
             --last;
@@ -446,7 +527,7 @@ struct StdSortGE {
                     oob = true;
                     break;
                 }
-                if (!ge(pv, b[last])) break;
+                if (!ge(pv, get(last))) break;
                 --last;
             }
             if (!(first < last)) return first;
@@ -454,25 +535,24 @@ struct StdSortGE {
             ++first;
         }
     }
-    __device__ void run() {
+    // stack: LDS scratch of 3*kSortStack ints (explicit form of __introsort_loop's recursion)
+    __device__ void run(int *stk) {
         oob = false;
         if (n <= 0) return;
         int lg = 0;
         while ((1 << (lg + 1)) <= n) lg++;
-        // __introsort_loop with its tail recursion made explicit: recurse on [cut, last), loop on [first, cut)
-        int stack_first[40], stack_last[40], stack_depth[40];
         int sp = 0;
-        stack_first[0] = 0;
-        stack_last[0] = n;
-        stack_depth[0] = 2 * lg;
+        stk[0] = 0;
+        stk[1] = n;
+        stk[2] = 2 * lg;
         sp = 1;
         while (sp > 0) {
             --sp;
-            const int first = stack_first[sp];
-            int last = stack_last[sp];
-            int depth = stack_depth[sp];
-            // libstdc++ handles the right part FIRST (recursive call) and then continues with the left part.
-            // The two parts are disjoint, so the order in which they are processed does not change the result.
+            const int first = stk[3 * sp];
+            int last = stk[3 * sp + 1];
+            int depth = stk[3 * sp + 2];
+            // libstdc++ recurses into the right part and loops on the left part; the parts are disjoint, so the
+            // order in which they are processed does not change the result.
             while (last - first > 16) {
                 if (depth == 0) {
                     heapsort(first, last);
@@ -483,10 +563,10 @@ struct StdSortGE {
                 move_median_to_first(first, first + 1, mid, last - 1);
                 int cut = unguarded_partition(first + 1, last, first);
                 if (cut > last) cut = last;  // only after an out-of-bounds scan
-                if (sp < 40) {
-                    stack_first[sp] = cut;
-                    stack_last[sp] = last;
-                    stack_depth[sp] = depth;
+                if (sp < kSortStack) {
+                    stk[3 * sp] = cut;
+                    stk[3 * sp + 1] = last;
+                    stk[3 * sp + 2] = depth;
                     ++sp;
                 }
                 last = cut;
@@ -534,21 +614,61 @@ __device__ __forceinline__ bool score_pair(const Sampler &smp, int ax, int ay, f
     return true;
 }
 
-// Shared tail of K_B: ordered candidate compaction, the reference's sort, greedy matching (pafprocess.cpp:108-130)
+// K_B working set in LDS (after the map): peaks of the two parts, the accepted candidates (generation order) and
+// the matching state.  Bytes: 40*maxp + 28*cap.
 struct LimbLds {
-    int *ax, *ay, *bx, *by;
-    float *as, *bs;
-    SortElem *sort;      // [cap]
-    float *c_score;      // [cap]  criterion2
-    float *c_len;        // [cap]
-    unsigned *c_idx;     // [cap]  ia | ib << 16
+    int *ax, *ay, *bx, *by;   // [maxp] Peak.x / Peak.y (ints)
+    float *as, *bs;           // [maxp] Peak.score
+    int *minA, *minB;         // [maxp] lowest rank among live candidates touching this endpoint
+    int *usedA, *usedB;       // [maxp]
+    float *key;               // [cap] overall_score
+    int *rank;                // [cap] position of candidate g in the reference's sorted order
+    int *order;               // [cap] inverse: candidate at sorted position r
+    int *state;               // [cap] 0 live, 1 accepted, 2 dead
+    float *c_score;           // [cap] criterion2
+    float *c_len;             // [cap]
+    unsigned *c_idx;          // [cap] ia | ib << 16
 };
+__host__ __device__ inline size_t limb_lds_bytes(int maxp, int cap) { return 40 * (size_t)maxp + 28 * (size_t)cap; }
 
+__device__ inline LimbLds carve_limb_lds(unsigned char *p, int maxp, int cap) {
+    LimbLds L;
+    int *q = reinterpret_cast<int *>(p);
+    L.ax = q; q += maxp;
+    L.ay = q; q += maxp;
+    L.bx = q; q += maxp;
+    L.by = q; q += maxp;
+    L.as = reinterpret_cast<float *>(q); q += maxp;
+    L.bs = reinterpret_cast<float *>(q); q += maxp;
+    L.minA = q; q += maxp;
+    L.minB = q; q += maxp;
+    L.usedA = q; q += maxp;
+    L.usedB = q; q += maxp;
+    L.key = reinterpret_cast<float *>(q); q += cap;
+    L.rank = q; q += cap;
+    L.order = q; q += cap;
+    L.state = q; q += cap;
+    L.c_score = reinterpret_cast<float *>(q); q += cap;
+    L.c_len = reinterpret_cast<float *>(q); q += cap;
+    L.c_idx = reinterpret_cast<unsigned *>(q);
+    return L;
+}
+
+// pafprocess.cpp:51-130 for one limb, all 256 threads:
+//  1. score every (a, b) pair (one lane each), ordered compaction of the accepted ones (generation order)
+//  2. rank of every candidate in the reference's sorted order (parallel; exact tie semantics, see StdSortGE)
+//  3. greedy matching as repeated acceptance of locally dominant candidates: a live candidate whose rank is the
+//     lowest among the live candidates sharing its a-peak AND among those sharing its b-peak is exactly a
+//     candidate the sequential scan of :113-129 accepts; endpoints are then retired.  Ranks are distinct, so this
+//     yields the same set as the sequential greedy pick (and min(nA, nB) of :111 can never bind earlier).
+//  4. accepted connections written in rank order (the order the assembly consumes them in).
 template <typename Sampler>
 __device__ void connect_limb(const Sampler &smp, const LimbLds &L, int nA, int nB, int cap, int maxp, int min_img_size,
                              float4 *__restrict__ conn_out, int *__restrict__ conn_count,
                              unsigned *__restrict__ status_word) {
     __shared__ int s_wcnt[2][kWaves];
+    __shared__ int s_stack[3 * kSortStack];
+    __shared__ int s_oob;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int npairs = nA * nB;
     int ncand = 0;  // uniform across the workgroup
@@ -577,8 +697,7 @@ __device__ void connect_limb(const Sampler &smp, const LimbLds &L, int nA, int n
         if (ok) {
             const int pos = ncand + before + __popcll(m & lanemask_lt());
             if (pos < cap) {
-                L.sort[pos].key = overall;
-                L.sort[pos].gen = pos;
+                L.key[pos] = overall;
                 L.c_score[pos] = c2;
                 L.c_len[pos] = len;
                 L.c_idx[pos] = (unsigned)ia | ((unsigned)ib << 16);
@@ -586,43 +705,129 @@ __device__ void connect_limb(const Sampler &smp, const LimbLds &L, int nA, int n
         }
         ncand += all;
     }
+    unsigned st = 0;
+    if (ncand > cap) {
+        st |= PP_ST_CAND_OVERFLOW;
+        ncand = cap;
+    }
+    const int n = ncand;
+    if (threadIdx.x == 0) s_oob = 0;
+    for (int i = threadIdx.x; i < maxp; i += kThreads) {
+        L.usedA[i] = 0;
+        L.usedB[i] = 0;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned st = 0;
-        if (ncand > cap) {
-            st |= PP_ST_CAND_OVERFLOW;
-            ncand = cap;
-        }
-        StdSortGE srt;
-        srt.b = L.sort;
-        srt.n = ncand;
-        srt.run();
-        if (srt.oob) st |= PP_ST_SORT_UNDEFINED;
-        // greedy pick, :111-129
-        const int max_conn = nA < nB ? nA : nB;
-        unsigned long long ua0 = 0, ua1 = 0, ub0 = 0, ub1 = 0;
-        int ncn = 0;
-        for (int k = 0; k < ncand && ncn < max_conn; k++) {
-            const int g = L.sort[k].gen;
-            const unsigned idx = L.c_idx[g];
-            const int ia = (int)(idx & 0xffffu), ib = (int)(idx >> 16);
-            const unsigned long long ma = 1ull << (ia & 63), mb = 1ull << (ib & 63);
-            const bool a_used = ((ia < 64 ? ua0 : ua1) & ma) != 0;
-            const bool b_used = ((ib < 64 ? ub0 : ub1) & mb) != 0;
-            if (!a_used && !b_used) {
-                if (ia < 64) ua0 |= ma; else ua1 |= ma;
-                if (ib < 64) ub0 |= mb; else ub1 |= mb;
-                conn_out[ncn] = make_float4(__int_as_float(ia), __int_as_float(ib), L.c_score[g], L.c_len[g]);
-                ncn++;
+
+    // ---- 2. ranks
+    bool tie = false;
+    for (int t = threadIdx.x; t < n; t += kThreads) {
+        const float kt = L.key[t];
+        int gt = 0, eq_later = 0, eq_any = 0;
+        for (int j = 0; j < n; j++) {
+            const float kj = L.key[j];  // broadcast read
+            gt += kj > kt;
+            if (kj == kt) {
+                eq_any += j != t;
+                eq_later += j > t;
             }
         }
+        // n <= 16 is a pure insertion sort with `>=`: an element moves in front of every earlier EQUAL element, so
+        // among equals the later-generated comes first.  Without ties eq_later is 0 and the order is unique.
+        L.rank[t] = gt + eq_later;
+        L.state[t] = 0;
+        tie |= eq_any > 0;
+    }
+    const int any_tie = __syncthreads_or(tie);
+    if (n > 16 && any_tie) {
+        for (int t = threadIdx.x; t < n; t += kThreads) L.order[t] = t;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            StdSortGE srt;
+            srt.key = L.key;  // sorted in place: the generation-indexed copy is no longer needed
+            srt.gen = L.order;
+            srt.n = n;
+            srt.run(s_stack);
+            if (srt.oob) s_oob = 1;
+        }
+        __syncthreads();
+        for (int r = threadIdx.x; r < n; r += kThreads) L.rank[L.order[r]] = r;
+    } else {
+        for (int t = threadIdx.x; t < n; t += kThreads) L.order[L.rank[t]] = t;
+    }
+    __syncthreads();
+    if (s_oob) st |= PP_ST_SORT_UNDEFINED;
+
+    // ---- 3. greedy matching by local dominance
+    while (true) {
+        for (int i = threadIdx.x; i < maxp; i += kThreads) {
+            L.minA[i] = 0x7fffffff;
+            L.minB[i] = 0x7fffffff;
+        }
+        __syncthreads();
+        bool live = false;
+        for (int t = threadIdx.x; t < n; t += kThreads) {
+            if (L.state[t] == 0) {
+                const unsigned idx = L.c_idx[t];
+                const int ia = (int)(idx & 0xffffu), ib = (int)(idx >> 16);
+                if (L.usedA[ia] || L.usedB[ib]) {
+                    L.state[t] = 2;
+                } else {
+                    atomicMin(&L.minA[ia], L.rank[t]);
+                    atomicMin(&L.minB[ib], L.rank[t]);
+                    live = true;
+                }
+            }
+        }
+        if (!__syncthreads_or(live)) break;
+        for (int t = threadIdx.x; t < n; t += kThreads) {
+            if (L.state[t] == 0) {
+                const unsigned idx = L.c_idx[t];
+                const int ia = (int)(idx & 0xffffu), ib = (int)(idx >> 16);
+                const int r = L.rank[t];
+                if (L.minA[ia] == r && L.minB[ib] == r) {
+                    L.state[t] = 1;
+                    L.usedA[ia] = 1;
+                    L.usedB[ib] = 1;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- 4. ordered output
+    int ncn = 0;
+    for (int base = 0; base < n; base += kThreads, buf ^= 1) {
+        const int r = base + threadIdx.x;
+        bool acc = false;
+        int t = 0;
+        if (r < n) {
+            t = L.order[r];
+            acc = L.state[t] == 1;
+        }
+        const unsigned long long m = __ballot(acc);
+        if (lane == 0) s_wcnt[buf][wave] = __popcll(m);
+        __syncthreads();
+        int before = 0, all = 0;
+#pragma unroll
+        for (int k = 0; k < kWaves; k++) {
+            const int c = s_wcnt[buf][k];
+            if (k < wave) before += c;
+            all += c;
+        }
+        if (acc) {
+            const unsigned idx = L.c_idx[t];
+            conn_out[ncn + before + __popcll(m & lanemask_lt())] =
+                make_float4(__int_as_float((int)(idx & 0xffffu)), __int_as_float((int)(idx >> 16)), L.c_score[t], L.c_len[t]);
+        }
+        ncn += all;
+    }
+    if (threadIdx.x == 0) {
         *conn_count = ncn;
         if (st) atomicOr(status_word, st);
     }
-    (void)maxp;
 }
 
-// LDS layout (dynamic): [map h*w T][cubic 16 f32][peaks: 6 arrays x maxp][sort cap x 8][c_score cap][c_len cap][c_idx cap]
+// LDS layout (dynamic): [map h*w T][cubic 16 f32][LimbLds: 40*maxp + 28*cap bytes]
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_limb_connect(const T *__restrict__ net, int n_samples, int h, int w,
                                                            int flip, int maxp, int cap, int min_img_size,
@@ -647,18 +852,7 @@ __global__ __launch_bounds__(kThreads) void k_limb_connect(const T *__restrict__
     off += (sizeof(T) * (size_t)npix + 15) & ~(size_t)15;
     float *s_cub = reinterpret_cast<float *>(lds_raw + off);
     off += 64;
-    LimbLds L;
-    L.ax = reinterpret_cast<int *>(lds_raw + off); off += 4 * (size_t)maxp;
-    L.ay = reinterpret_cast<int *>(lds_raw + off); off += 4 * (size_t)maxp;
-    L.bx = reinterpret_cast<int *>(lds_raw + off); off += 4 * (size_t)maxp;
-    L.by = reinterpret_cast<int *>(lds_raw + off); off += 4 * (size_t)maxp;
-    L.as = reinterpret_cast<float *>(lds_raw + off); off += 4 * (size_t)maxp;
-    L.bs = reinterpret_cast<float *>(lds_raw + off); off += 4 * (size_t)maxp;
-    off = (off + 7) & ~(size_t)7;
-    L.sort = reinterpret_cast<SortElem *>(lds_raw + off); off += 8 * (size_t)cap;
-    L.c_score = reinterpret_cast<float *>(lds_raw + off); off += 4 * (size_t)cap;
-    L.c_len = reinterpret_cast<float *>(lds_raw + off); off += 4 * (size_t)cap;
-    L.c_idx = reinterpret_cast<unsigned *>(lds_raw + off);
+    LimbLds L = carve_limb_lds(lds_raw + off, maxp, cap);
 
     if (threadIdx.x < 16) s_cub[threadIdx.x] = d_cubic4[threadIdx.x >> 2][threadIdx.x & 3];
     const float4 *pka = peaks + ((size_t)img * PP_NUM_PART + pa) * maxp;
@@ -705,18 +899,7 @@ __global__ __launch_bounds__(kThreads) void k_limb_connect_hwc(const float *__re
         return;
     }
     size_t off = 0;
-    LimbLds L;
-    L.ax = reinterpret_cast<int *>(lds_raw + off); off += 4 * (size_t)maxp;
-    L.ay = reinterpret_cast<int *>(lds_raw + off); off += 4 * (size_t)maxp;
-    L.bx = reinterpret_cast<int *>(lds_raw + off); off += 4 * (size_t)maxp;
-    L.by = reinterpret_cast<int *>(lds_raw + off); off += 4 * (size_t)maxp;
-    L.as = reinterpret_cast<float *>(lds_raw + off); off += 4 * (size_t)maxp;
-    L.bs = reinterpret_cast<float *>(lds_raw + off); off += 4 * (size_t)maxp;
-    off = (off + 7) & ~(size_t)7;
-    L.sort = reinterpret_cast<SortElem *>(lds_raw + off); off += 8 * (size_t)cap;
-    L.c_score = reinterpret_cast<float *>(lds_raw + off); off += 4 * (size_t)cap;
-    L.c_len = reinterpret_cast<float *>(lds_raw + off); off += 4 * (size_t)cap;
-    L.c_idx = reinterpret_cast<unsigned *>(lds_raw + off);
+    LimbLds L = carve_limb_lds(lds_raw + off, maxp, cap);
     const float4 *pka = peaks + (size_t)pa * maxp;
     const float4 *pkb = peaks + (size_t)pb * maxp;
     for (int i = threadIdx.x; i < nA; i += kThreads) {
@@ -742,7 +925,11 @@ __global__ __launch_bounds__(kThreads) void k_limb_connect_hwc(const float *__re
 // The scan over live skeletons (pafprocess.cpp:143-150) is done by the 64 lanes with ballots; the matched
 // skeleton(s) are then updated by lane 0 with the reference's exact statement order.
 constexpr int kMaxSkel = 256;
-constexpr int kSkelStride = 20;
+constexpr int kSkelStride = 21;  // 20 entries, odd stride: the per-lane column reads of the scan are conflict-free
+
+__host__ __device__ inline size_t assemble_lds_bytes(int maxp) {
+    return (size_t)kMaxSkel * kSkelStride * 8 + (size_t)PP_NUM_PART * maxp * 16 + (size_t)PP_NUM_LIMB * maxp * 16;
+}
 
 __global__ __launch_bounds__(64) void k_assemble(int maxp, int explicit_ids, const float4 *__restrict__ peaks,
                                                  const int *__restrict__ counts, const float4 *__restrict__ conns,
@@ -751,14 +938,16 @@ __global__ __launch_bounds__(64) void k_assemble(int maxp, int explicit_ids, con
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int img = blockIdx.x, lane = threadIdx.x;
     const int ntab = PP_NUM_PART * maxp;
-    int *sk_id = reinterpret_cast<int *>(lds_raw);                       // [kMaxSkel][20]
+    int *sk_id = reinterpret_cast<int *>(lds_raw);                          // [kMaxSkel][21]
     float *sk_sc = reinterpret_cast<float *>(sk_id + kMaxSkel * kSkelStride);
     int *line_x = reinterpret_cast<int *>(sk_sc + kMaxSkel * kSkelStride);  // peak_infos_line, bucket order
     int *line_y = line_x + ntab;
     float *line_s = reinterpret_cast<float *>(line_y + ntab);
-    int *ids = reinterpret_cast<int *>(line_s + ntab);                   // [18][maxp] peak id of (part, rank)
+    int *ids = reinterpret_cast<int *>(line_s + ntab);                      // [18][maxp] peak id of (part, rank)
+    float4 *s_conn = reinterpret_cast<float4 *>(ids + ntab);                // all connections, limb-major, compact
     __shared__ int s_off[PP_NUM_PART + 1];
     __shared__ int s_cnt[PP_NUM_PART];
+    __shared__ int s_coff[PP_NUM_LIMB + 1];
     __shared__ int s_merge;
 
     const int *cnt_g = counts + img * PP_NUM_PART;
@@ -773,6 +962,13 @@ __global__ __launch_bounds__(64) void k_assemble(int maxp, int explicit_ids, con
             run += c;
         }
         s_off[PP_NUM_PART] = run;
+        run = 0;
+        for (int l = 0; l < PP_NUM_LIMB; l++) {
+            s_coff[l] = run;
+            int c = conn_counts[img * PP_NUM_LIMB + l];
+            run += c < maxp ? c : maxp;
+        }
+        s_coff[PP_NUM_LIMB] = run;
     }
     __syncthreads();
     const int n_peaks = s_off[PP_NUM_PART];
@@ -787,18 +983,32 @@ __global__ __launch_bounds__(64) void k_assemble(int maxp, int explicit_ids, con
         }
     }
     __syncthreads();
+    // every connection of the image into LDS in one sweep (independent loads, all in flight), with the
+    // (part, rank) endpoints already translated to peak ids
+    for (int limb = 0; limb < PP_NUM_LIMB; limb++) {
+        const int c = s_coff[limb + 1] - s_coff[limb], o = s_coff[limb];
+        const int part1 = d_limb_pairs[limb][0], part2 = d_limb_pairs[limb][1];
+        const float4 *cn_g = conns + ((size_t)img * PP_NUM_LIMB + limb) * maxp;
+        for (int ci = lane; ci < c; ci += 64) {
+            float4 cn = cn_g[ci];
+            cn.x = __int_as_float(ids[part1 * maxp + __float_as_int(cn.x)]);
+            cn.y = __int_as_float(ids[part2 * maxp + __float_as_int(cn.y)]);
+            s_conn[o + ci] = cn;
+        }
+    }
+    __syncthreads();
 
     int nskel = 0;  // uniform
     unsigned st = 0;
     for (int limb = 0; limb < PP_NUM_LIMB; limb++) {
         const int part1 = d_limb_pairs[limb][0], part2 = d_limb_pairs[limb][1];
-        const int nconn = conn_counts[img * PP_NUM_LIMB + limb];
-        const float4 *cn_g = conns + ((size_t)img * PP_NUM_LIMB + limb) * maxp;
-        for (int ci = 0; ci < nconn; ci++) {
-            const float4 cn = cn_g[ci];
-            const int cid1 = __float_as_int(cn.x), cid2 = __float_as_int(cn.y);
+        for (int ci = s_coff[limb]; ci < s_coff[limb + 1]; ci++) {
+            const float4 cn = s_conn[ci];
+            const int id1 = __float_as_int(cn.x), id2 = __float_as_int(cn.y);
             const float c_score = cn.z, c_len = cn.w;
-            const int id1 = ids[part1 * maxp + cid1], id2 = ids[part2 * maxp + cid2];
+            // pl[id].score with the reference's indexing BY ID into the bucket-ordered line (:162)
+            const float ps1 = (id1 >= 0 && id1 < n_peaks) ? line_s[id1] : 0.0f;
+            const float ps2 = (id2 >= 0 && id2 < n_peaks) ? line_s[id2] : 0.0f;
             // ---- :143-150 scan all live skeletons
             int num_found = 0, idx1 = 0, idx2 = 0;
             for (int base = 0; base < nskel; base += 64) {
@@ -806,29 +1016,30 @@ __global__ __launch_bounds__(64) void k_assemble(int maxp, int explicit_ids, con
                 bool hit = false;
                 if (s < nskel) hit = (sk_id[s * kSkelStride + part1] == id1) || (sk_id[s * kSkelStride + part2] == id2);
                 unsigned long long m = __ballot(hit);
-                while (m) {
-                    const int l = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    if (num_found == 0) idx1 = base + l;
-                    if (num_found == 1) idx2 = base + l;
-                    num_found++;
+                if (m) {
+                    if (num_found == 0) {
+                        idx1 = base + __ffsll((long long)m) - 1;
+                        const unsigned long long m2 = m & (m - 1);
+                        if (m2) idx2 = base + __ffsll((long long)m2) - 1;
+                    } else if (num_found == 1) {
+                        idx2 = base + __ffsll((long long)m) - 1;
+                    }
+                    num_found += __popcll(m);
                 }
             }
-            // pl[id].score with the reference's indexing BY ID into the bucket-ordered line (:162)
-            const float ps1 = (id1 >= 0 && id1 < n_peaks) ? line_s[id1] : 0.0f;
-            const float ps2 = (id2 >= 0 && id2 < n_peaks) ? line_s[id2] : 0.0f;
             if (num_found == 1) {  // :152-180
                 if (lane == 0) {
                     int *i1 = sk_id + idx1 * kSkelStride;
                     float *f1 = sk_sc + idx1 * kSkelStride;
-                    const int min_len = (int)__fmul_rn(f1[19], 16.0f);  // :154 int truncation of length*LIMB_LENGTH_RATE
+                    const float len1 = f1[19];
+                    const int min_len = (int)__fmul_rn(len1, 16.0f);  // :154 int truncation of length*LIMB_LENGTH_RATE
                     const int cur_id = i1[part2];
                     const float cur_sc = f1[part2];
                     if (cur_id == -1 && (float)min_len > c_len) {
                         i1[part2] = id2;
                         f1[part2] = c_score;
                         i1[19] += 1;
-                        f1[19] = f1[19] < c_len ? c_len : f1[19];
+                        f1[19] = len1 < c_len ? c_len : len1;
                         f1[18] = __fadd_rn(f1[18], __fadd_rn(ps2, c_score));
                     } else if ((cur_id != id2 && cur_sc <= c_score && (float)min_len > c_len) ||
                                (cur_id == id2 && cur_sc <= c_score)) {
@@ -838,7 +1049,7 @@ __global__ __launch_bounds__(64) void k_assemble(int maxp, int explicit_ids, con
                         f1[part2] = c_score;
                         const float t = __fadd_rn(ps2, c_score);
                         f1[18] = __fadd_rn(__fadd_rn(f1[18], -t), t);
-                        f1[19] = f1[19] < c_len ? c_len : f1[19];
+                        f1[19] = len1 < c_len ? c_len : len1;
                     }
                 }
                 __syncthreads();
@@ -874,7 +1085,7 @@ __global__ __launch_bounds__(64) void k_assemble(int maxp, int explicit_ids, con
                 __syncthreads();
                 if (s_merge) {  // skeletons.erase(begin + idx2): shift the tail down one slot (:228)
                     for (int s = idx2; s < nskel - 1; s++) {
-                        if (lane < kSkelStride) {
+                        if (lane < 20) {
                             sk_id[s * kSkelStride + lane] = sk_id[(s + 1) * kSkelStride + lane];
                             sk_sc[s * kSkelStride + lane] = sk_sc[(s + 1) * kSkelStride + lane];
                         }
@@ -884,7 +1095,7 @@ __global__ __launch_bounds__(64) void k_assemble(int maxp, int explicit_ids, con
                 __syncthreads();
             } else if (num_found == 0) {  // :257-273
                 if (nskel < kMaxSkel) {
-                    if (lane < kSkelStride) {
+                    if (lane < 20) {
                         int idv = -1;
                         float scv = -1.0f;
                         if (lane == part1) { idv = id1; scv = c_score; }
@@ -907,10 +1118,6 @@ __global__ __launch_bounds__(64) void k_assemble(int maxp, int explicit_ids, con
     // ---- prune (:278-282) + records; order of survivors preserved
     pp_record *rec = records + img;
     int n_out = 0;
-    int n_conn_total = 0;
-    for (int l = lane; l < PP_NUM_LIMB; l += 64) n_conn_total += conn_counts[img * PP_NUM_LIMB + l];
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) n_conn_total += __shfl_xor(n_conn_total, d);
     for (int base = 0; base < nskel; base += 64) {
         const int s = base + lane;
         bool keep = false;
@@ -946,7 +1153,7 @@ __global__ __launch_bounds__(64) void k_assemble(int maxp, int explicit_ids, con
         }
         rec->n_humans = n_out;
         rec->n_peaks = n_peaks;
-        rec->n_connections = n_conn_total;
+        rec->n_connections = s_coff[PP_NUM_LIMB];
         rec->status = status[img] | st;
     }
 }
@@ -958,12 +1165,10 @@ size_t lds_bytes_heat(int elem, int h, int w, int maxp) {
 }
 size_t lds_bytes_limb(int elem, int h, int w, int maxp, int cap) {
     const size_t npix = (size_t)h * w;
-    return ((elem * npix + 15) & ~(size_t)15) + 64 + 24 * (size_t)maxp + 8 + 20 * (size_t)cap;
+    return ((elem * npix + 15) & ~(size_t)15) + 64 + limb_lds_bytes(maxp, cap);
 }
-size_t lds_bytes_limb_hwc(int maxp, int cap) { return 24 * (size_t)maxp + 8 + 20 * (size_t)cap; }
-size_t lds_bytes_assemble(int maxp) {
-    return (size_t)kMaxSkel * kSkelStride * 8 + (size_t)PP_NUM_PART * maxp * 16;
-}
+size_t lds_bytes_limb_hwc(int maxp, int cap) { return limb_lds_bytes(maxp, cap); }
+size_t lds_bytes_assemble(int maxp) { return assemble_lds_bytes(maxp); }
 
 // Dynamic LDS above the 64 KB default needs the attribute; set once per process (pp_create), not per launch, so
 // that the per-batch entry points stay free of anything but kernel launches (hipGraph-capturable).

@@ -20,6 +20,26 @@ from torch import nn
 LEAK = 0.01
 
 
+def hip_bias_act_(y: torch.Tensor, bias: torch.Tensor, res, act: bool) -> torch.Tensor:
+    """In place y = act(y + bias[c] (+ res)) by the fused HIP epilogue kernel (csrc/posepaf_epilogue.hip)."""
+    import ctypes as C
+    from . import _lib
+    if not y.is_contiguous(memory_format=torch.channels_last):
+        y = y.contiguous(memory_format=torch.channels_last)
+    if res is not None and not res.is_contiguous(memory_format=torch.channels_last):
+        res = res.contiguous(memory_format=torch.channels_last)
+    L = _lib.load()
+    rc = L.pp_bias_act_f16(C.c_void_p(y.data_ptr()), C.c_void_p(bias.data_ptr()),
+                           C.c_void_p(res.data_ptr()) if res is not None else None, y.numel(), y.shape[1], LEAK, int(act),
+                           C.c_void_p(torch.cuda.current_stream(y.device).cuda_stream))
+    _lib.check(rc)
+    return y
+
+
+def _use_hip(x: torch.Tensor, c_out: int) -> bool:
+    return x.is_cuda and x.dtype == torch.float16 and c_out % 8 == 0
+
+
 def _fold(conv: nn.Conv2d, bn: nn.BatchNorm2d | None):
     w = conv.weight.detach().float()
     b = conv.bias.detach().float() if conv.bias is not None else torch.zeros(w.shape[0], device=w.device)
@@ -41,8 +61,16 @@ class FConv(nn.Module):
         self.stride, self.padding, self.dilation = conv.stride, conv.padding, conv.dilation
         self.act = act
 
-    def forward(self, x):
+    def conv_only(self, x):
+        return F.conv2d(x, self.weight, None, self.stride, self.padding, self.dilation)
+
+    def forward(self, x, res=None):
+        """act(conv(x) + bias (+ res))"""
+        if _use_hip(x, self.weight.shape[0]):
+            return hip_bias_act_(self.conv_only(x), self.bias, res, self.act)
         y = F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation)
+        if res is not None:
+            y = y + res
         return F.leaky_relu_(y, LEAK) if self.act else y
 
 
@@ -57,13 +85,14 @@ class FResidual(nn.Module):
         self.c1 = FConv(cb[0], cb[1], True)
         self.c2 = FConv(cb[3], cb[4], True)
         self.c3 = FConv(cb[6], cb[7], False)
+        self.c3.act = r.relu_flag  # the block's final LeakyReLU is applied by c3's epilogue, after the skip add
         self.skip = FConv(r.skipConv[0], r.skipConv[1], False) if r.ins != r.outs else None
-        self.act = r.relu_flag
+        if self.skip is not None:  # conv3 + b3 + convs + bs: one bias vector, the skip conv runs bias-free
+            self.c3.bias = nn.Parameter(self.c3.bias + self.skip.bias, requires_grad=False)
 
     def forward(self, x):
-        y = self.c3(self.c2(self.c1(x)))
-        y += self.skip(x) if self.skip is not None else x
-        return F.leaky_relu_(y, LEAK) if self.act else y
+        res = self.skip.conv_only(x) if self.skip is not None else x
+        return self.c3(self.c2(self.c1(x)), res)
 
 
 class FHourglass(nn.Module):
@@ -128,6 +157,10 @@ class FusedIMHN(nn.Module):
         self.head = nn.ModuleList([nn.ModuleList([_fconv_from_block(c) for c in o]) for o in p.outs])
         self.mfeat = nn.ModuleList([nn.ModuleList([_fconv_from_block(m.conv) for m in ms]) for ms in p.merge_features])
         self.mpred = nn.ModuleList([nn.ModuleList([_fconv_from_block(m.conv) for m in ms]) for ms in p.merge_preds])
+        # cache_s = merge_pred(pred) + merge_feat(feat): both are bias-only 1x1 convs -> one epilogue with the summed bias
+        for mf, mp in zip(self.mfeat, self.mpred):
+            for f, q in zip(mf, mp):
+                f.bias = nn.Parameter(f.bias + q.bias, requires_grad=False)
 
     @classmethod
     def from_network(cls, net):
@@ -152,7 +185,7 @@ class FusedIMHN(nn.Module):
             preds = [self.head[t][s](feats[s]) for s in scales]
             if last:
                 return preds[0]
-            caches = [self.mpred[t][s](preds[s]) + self.mfeat[t][s](feats[s]) for s in scales]
+            caches = [self.mfeat[t][s](feats[s], self.mpred[t][s].conv_only(preds[s])) for s in scales]
             x = x + caches[0]
 
 

@@ -115,6 +115,12 @@ PP_API int pp_nms_batch(pp_ctx *ctx, int batch, const void *net_out_dev, int dty
 PP_API int pp_time_kernels(pp_ctx *ctx, int batch, const void *net_out_dev, int dtype, int h, int w, int flip,
                            int min_img_size, int iters, float *ms_out, void *stream);
 
+/* Forward-pass helper (not part of the reference's interface): fused convolution epilogue on a channels-last
+ * (NHWC) fp16 activation, in place: y = act(y + bias[c] (+ residual)), act = LeakyReLU(slope) if has_act.
+ * y/residual: DEVICE fp16, n_elems = N*H*W*C, channels % 8 == 0, 16-byte aligned; bias: DEVICE fp16[channels]. */
+PP_API int pp_bias_act_f16(void *y, const void *bias, const void *residual, long n_elems, int channels, float slope,
+                           int has_act, void *stream);
+
 /* Blocking read-backs of the context's workspace for the last batch (host pointers).
  * pp_read_peaks: joint_list rows [x, y, score, peak_id, part] (evaluate.py:99-103) of one image. */
 PP_API int pp_read_peaks(pp_ctx *ctx, int image, float *joint_list_host, int max_rows, int *n_rows);
