@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("POSEPAF_BENCH_BATCH", "16")),
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("POSEPAF_BENCH_BATCH", "32")),
                     help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="bound on the CPU baseline leg")
@@ -88,6 +88,9 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU path)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # MIOpen exhaustive find (miopenFindConvolutionForwardAlgorithm) per conv shape: +30 % over the default heuristic
+    if os.environ.get("POSEPAF_CUDNN_BENCHMARK", "1") == "1":
+        torch.backends.cudnn.benchmark = True
     dist = None
     if world > 1:
         import torch.distributed as dist
