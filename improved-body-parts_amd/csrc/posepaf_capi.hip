@@ -135,6 +135,10 @@ int pp_destroy(pp_ctx *ctx) {
 
 int pp_last_hip_error(const pp_ctx *ctx) { return ctx ? ctx->hip_err : 0; }
 
+int pp_debug_set_stamps(long long *stamps_dev) {
+    return pp::set_stamp_buffer(stamps_dev) == hipSuccess ? PP_OK : PP_ERR_HIP;
+}
+
 int pp_nms_batch(pp_ctx *ctx, int batch, const void *net_out_dev, int dtype, int h, int w, int flip, int refine,
                  float *peaks_dev, int *counts_dev, void *stream) {
     int rc = check_shape(ctx, batch, dtype, h, w);

@@ -11,6 +11,7 @@ namespace pp {
 // 160 KiB of LDS per CU (gfx950) minus room for the kernels' static __shared__ arrays (< 2 KB)
 constexpr size_t kMaxDynLds = 163840 - 4096;
 hipError_t init_kernel_attributes();
+hipError_t set_stamp_buffer(long long *buf);
 
 size_t lds_bytes_heat(int elem, int h, int w, int maxp);
 size_t lds_bytes_limb(int elem, int h, int w, int maxp, int cap);

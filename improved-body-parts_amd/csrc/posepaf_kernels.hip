@@ -46,12 +46,35 @@ __device__ const float d_cubic4[4][4] = {{-0.06591796875f, 0.42626953125f, 0.749
                                          {-0.07177734375f, 0.96728515625f, 0.11474609375f, -0.01025390625f},
                                          {-0.10986328125f, 0.74951171875f, 0.42626953125f, -0.06591796875f}};
 
+// Diagnostic phase stamps (shader clock) written per workgroup when a stamp buffer is registered with
+// pp_debug_set_stamps(); a null pointer (the default) costs one scalar branch per phase.
+__device__ long long *d_stamps = nullptr;
+__device__ __forceinline__ void stamp(long long *buf, int wg, int slot) {
+    if (buf && threadIdx.x == 0) buf[(size_t)wg * 8 + slot] = (long long)clock64();
+}
+
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ float ldsf(const float *p, int i) { return p[i]; }
 __device__ __forceinline__ float ldsf(const __half *p, int i) { return __half2float(p[i]); }
+// 8 consecutive map values starting at a multiple of 8 (16-byte aligned for binary16, two 16-byte reads for f32)
+__device__ __forceinline__ void load8(const __half *p, float out[8]) {
+    const uint4 q = *reinterpret_cast<const uint4 *>(p);
+    const __half2 *h2 = reinterpret_cast<const __half2 *>(&q);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const float2 f = __half22float2(h2[j]);
+        out[2 * j] = f.x;
+        out[2 * j + 1] = f.y;
+    }
+}
+__device__ __forceinline__ void load8(const float *p, float out[8]) {
+    const float4 a = reinterpret_cast<const float4 *>(p)[0], b = reinterpret_cast<const float4 *>(p)[1];
+    out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w;
+    out[4] = b.x; out[5] = b.y; out[6] = b.z; out[7] = b.w;
+}
 __device__ __forceinline__ unsigned long long lanemask_lt() {
     return (1ull << (threadIdx.x & 63)) - 1ull;
 }
@@ -180,6 +203,7 @@ __device__ __forceinline__ float bicubic4_at(const T *smap, int w, int x0, int y
     const int sx = ((X + 2) >> 2) - 1, sy = ((Y + 2) >> 2) - 1;
     const float4 ca = reinterpret_cast<const float4 *>(s_cub)[X & 3];
     const float4 cb = reinterpret_cast<const float4 *>(s_cub)[Y & 3];
+    // (an unclamped "interior" fast path was tried: the extra divergent branch made the kernel 1.2-1.8x slower)
     const int xi0 = x0 + clampi(sx - 1, 0, pw - 1), xi1 = x0 + clampi(sx, 0, pw - 1);
     const int xi2 = x0 + clampi(sx + 1, 0, pw - 1), xi3 = x0 + clampi(sx + 2, 0, pw - 1);
     float hrow[4];
@@ -200,8 +224,7 @@ __device__ __forceinline__ float bicubic4_at(const T *smap, int w, int x0, int y
 }
 
 // ------------------------------------------------------------------------------------------------ K_A
-// LDS layout (dynamic): [map: h*w T][cubic 16 f32][chunk masks u64 x nchunks][chunk offsets i32 x (nchunks+1)]
-//                       [peak linear index i32 x maxp]
+// LDS layout (dynamic): [map: h*w T][cubic 16 f32][peak linear index i32 x maxp][peak-mask bytes x ceil(h*w/8)]
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_heat_peaks(const T *__restrict__ net, int n_samples, int h, int w,
                                                          int flip, int refine, int nms_mode, float thr, int maxp,
@@ -210,19 +233,15 @@ __global__ __launch_bounds__(kThreads) void k_heat_peaks(const T *__restrict__ n
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int part = blockIdx.x, img = blockIdx.y;
     const int npix = h * w;
-    const int nchunks = (npix + 63) >> 6;
     size_t off = 0;
     T *smap = reinterpret_cast<T *>(lds_raw);
     off += (sizeof(T) * (size_t)npix + 15) & ~(size_t)15;
     float *s_cub = reinterpret_cast<float *>(lds_raw + off);
     off += 64;
-    unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(lds_raw + off);
-    off += sizeof(unsigned long long) * (size_t)nchunks;
-    int *s_off = reinterpret_cast<int *>(lds_raw + off);
-    off += sizeof(int) * (size_t)(nchunks + 4);
     int *s_pk = reinterpret_cast<int *>(lds_raw + off);
+    off += (4 * (size_t)maxp + 15) & ~(size_t)15;
+    unsigned char *s_m8 = lds_raw + off;  // one peak-mask byte per 8-pixel vector
     __shared__ int s_wsum[kWaves];
-    __shared__ int s_total;
     __shared__ float s_hpass[kWaves][5 * 20];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -231,80 +250,141 @@ __global__ __launch_bounds__(kThreads) void k_heat_peaks(const T *__restrict__ n
     const size_t plane = (size_t)npix;
     const T *o0 = net + ((size_t)img * n_samples * PP_NUM_CH + PP_NUM_LIMB + part) * plane;
     const T *o1 = net + (((size_t)img * n_samples + 1) * PP_NUM_CH + PP_NUM_LIMB + d_flip_heat_ord[part]) * plane;
+    long long *stamps = d_stamps;
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    stamp(stamps, wg, 0);
     load_channel(smap, o0, o1, h, w, flip != 0);
     __syncthreads();
+    stamp(stamps, wg, 1);
 
-    // ---- A3: local maxima, 64 consecutive row-major pixels per wave step, one ballot each
-    {
-        const int step = kWaves * 64;
-        const int dy = step / w, dx = step - dy * w;
-        int i = (wave << 6) + lane;
-        int y = i / w, x = i - y * w;
-        for (int chunk = wave; chunk < nchunks; chunk += kWaves, i += step) {
-            bool pk = false;
-            if (i < npix) {
-                const float v = ldsf(smap, i);
-                const bool above = nms_mode == 0 ? (v > thr) : (v >= thr);  // parse_skeletons.py:116 / util.py:184
-                if (above) {
-                    pk = true;
-                    if (y > 0 && ldsf(smap, i - w) > v) pk = false;
-                    if (y < h - 1 && ldsf(smap, i + w) > v) pk = false;
-                    if (x > 0 && ldsf(smap, i - 1) > v) pk = false;
-                    if (x < w - 1 && ldsf(smap, i + 1) > v) pk = false;
-                    if (nms_mode != 0) {  // full 3x3 window (utils/util.py:181-184)
-                        if (y > 0 && x > 0 && ldsf(smap, i - w - 1) > v) pk = false;
-                        if (y > 0 && x < w - 1 && ldsf(smap, i - w + 1) > v) pk = false;
-                        if (y < h - 1 && x > 0 && ldsf(smap, i + w - 1) > v) pk = false;
-                        if (y < h - 1 && x < w - 1 && ldsf(smap, i + w + 1) > v) pk = false;
-                    }
-                }
-            }
-            const unsigned long long m = __ballot(pk);
-            if (lane == 0) s_mask[chunk] = m;
-            x += dx;
-            y += dy;
-            if (x >= w) {
-                x -= w;
-                y += 1;
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- exclusive scan of the per-chunk populations (np.nonzero order == ascending linear index)
-    {
-        const int cpt = (nchunks + kThreads - 1) / kThreads;  // chunks per thread
-        const int c0 = threadIdx.x * cpt;
-        int local = 0;
-        for (int c = c0; c < c0 + cpt && c < nchunks; c++) local += __popcll(s_mask[c]);
-        int incl = local;
+    // ---- A3: local maxima.  Each lane tests 8 consecutive row-major pixels per step (one 16-byte LDS read for
+    // binary16 maps); only pixels above the threshold (a few per cent) go on to the neighbour reads.  Peak order must
+    // be np.nonzero's (ascending linear index): per-(step, wave) counts -> block prefix -> lane prefix -> bit rank.
+    const int nvec = (npix + 7) >> 3;
+    const int nk = (nvec + kThreads - 1) / kThreads;  // steps; <= kMaxSteps is checked on the host
+    const bool rows_aligned = (w & 7) == 0;  // then an 8-pixel vector never straddles two rows
+    auto mask8 = [&](int v) -> unsigned {
+        const int i0 = v << 3;
+        if (i0 >= npix) return 0u;
+        float val[8];
+        if (i0 + 8 <= npix) {
+            load8(smap + i0, val);
+        } else {
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int n = __shfl_up(incl, d);
-            if (lane >= d) incl += n;
+            for (int j = 0; j < 8; j++) val[j] = i0 + j < npix ? ldsf(smap, i0 + j) : -INFINITY;
         }
-        if (lane == 63) s_wsum[wave] = incl;
-        __syncthreads();
-        int base = 0;
-        for (int k = 0; k < wave; k++) base += s_wsum[k];
-        int run = base + incl - local;
-        for (int c = c0; c < c0 + cpt && c < nchunks; c++) {
-            s_off[c] = run;
-            run += __popcll(s_mask[c]);
+        unsigned above = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (nms_mode == 0 ? (val[j] > thr) : (val[j] >= thr)) above |= 1u << j;  // parse_skeletons.py:116 / util.py:184
+        if (above == 0) return 0u;
+        unsigned m = 0;
+        if (rows_aligned) {
+            // branch-free form: the rows above/below as two more 16-byte reads, the horizontal neighbours from the
+            // vector itself plus one scalar on each side; out-of-map neighbours are -inf (never greater)
+            const int y = i0 / w, x0 = i0 - y * w;
+            float up[8], dn[8];
+            if (y > 0) load8(smap + i0 - w, up);
+            if (y < h - 1) load8(smap + i0 + w, dn);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                if (y == 0) up[j] = -INFINITY;
+                if (y == h - 1) dn[j] = -INFINITY;
+            }
+            const float lft = x0 > 0 ? ldsf(smap, i0 - 1) : -INFINITY;
+            const float rgt = x0 + 8 < w ? ldsf(smap, i0 + 8) : -INFINITY;
+            float ul = -INFINITY, ur = -INFINITY, dl = -INFINITY, dr = -INFINITY;
+            if (nms_mode != 0) {
+                if (y > 0 && x0 > 0) ul = ldsf(smap, i0 - w - 1);
+                if (y > 0 && x0 + 8 < w) ur = ldsf(smap, i0 - w + 8);
+                if (y < h - 1 && x0 > 0) dl = ldsf(smap, i0 + w - 1);
+                if (y < h - 1 && x0 + 8 < w) dr = ldsf(smap, i0 + w + 8);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float vj = val[j];
+                bool pk = !(up[j] > vj) && !(dn[j] > vj);
+                pk = pk && !((j > 0 ? val[j - 1] : lft) > vj) && !((j < 7 ? val[j + 1] : rgt) > vj);
+                if (nms_mode != 0) {  // full 3x3 window (utils/util.py:181-184)
+                    pk = pk && !((j > 0 ? up[j - 1] : ul) > vj) && !((j < 7 ? up[j + 1] : ur) > vj);
+                    pk = pk && !((j > 0 ? dn[j - 1] : dl) > vj) && !((j < 7 ? dn[j + 1] : dr) > vj);
+                }
+                if (pk) m |= 1u << j;
+            }
+            return m & above;
         }
-        if (threadIdx.x == kThreads - 1) s_total = run;
-        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (above & (1u << j)) {
+                const float vj = val[j];
+                const int i = i0 + j;
+                const int y = i / w, x = i - y * w;
+                bool pk = true;
+                if (y > 0 && ldsf(smap, i - w) > vj) pk = false;
+                if (y < h - 1 && ldsf(smap, i + w) > vj) pk = false;
+                if (x > 0 && ldsf(smap, i - 1) > vj) pk = false;
+                if (x < w - 1 && ldsf(smap, i + 1) > vj) pk = false;
+                if (nms_mode != 0) {
+                    if (y > 0 && x > 0 && ldsf(smap, i - w - 1) > vj) pk = false;
+                    if (y > 0 && x < w - 1 && ldsf(smap, i - w + 1) > vj) pk = false;
+                    if (y < h - 1 && x > 0 && ldsf(smap, i + w - 1) > vj) pk = false;
+                    if (y < h - 1 && x < w - 1 && ldsf(smap, i + w + 1) > vj) pk = false;
+                }
+                if (pk) m |= 1u << j;
+            }
+        }
+        return m;
+    };
+    for (int k = 0; k < nk; k++) {
+        const int v = k * kThreads + threadIdx.x;
+        const unsigned m8 = mask8(v);
+        if (v < nvec) s_m8[v] = (unsigned char)m8;
     }
-    const int total = s_total;
+    __syncthreads();
+    // Thread t now owns mask bytes [t*bpt, (t+1)*bpt), i.e. a CONTIGUOUS pixel range, so peak order (np.nonzero:
+    // ascending linear index) is thread order: one block scan of the per-thread counts gives every peak's rank.
+    const int bpt = nk;  // == ceil(nvec / kThreads)
+    const int b0 = threadIdx.x * bpt;
+    int cnt = 0;
+    unsigned long long word = 0;
+    const bool one_word = bpt == 8;  // the 128 x 128 case: a thread's 64 pixels are one 8-byte LDS read
+    if (one_word) {
+        word = b0 + 8 <= nvec ? *reinterpret_cast<const unsigned long long *>(s_m8 + b0) : 0ull;
+        cnt = __popcll(word);
+    } else {
+        for (int q = b0; q < b0 + bpt && q < nvec; q++) cnt += __popc((unsigned)s_m8[q]);
+    }
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int n = __shfl_up(incl, d);
+        if (lane >= d) incl += n;
+    }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    int rank = incl - cnt;
+    for (int q = 0; q < wave; q++) rank += s_wsum[q];
+    int total = 0;
+    for (int q = 0; q < kWaves; q++) total += s_wsum[q];
     const int kept = total < maxp ? total : maxp;
-    for (int chunk = wave; chunk < nchunks; chunk += kWaves) {
-        const unsigned long long m = s_mask[chunk];
-        if ((m >> lane) & 1ull) {
-            const int rank = s_off[chunk] + __popcll(m & lanemask_lt());
-            if (rank < maxp) s_pk[rank] = (chunk << 6) + lane;
+    if (one_word) {
+        while (word && rank < maxp) {
+            const int bit = __ffsll((long long)word) - 1;
+            word &= word - 1;
+            s_pk[rank++] = (b0 << 3) + bit;
+        }
+    } else {
+        for (int q = b0; q < b0 + bpt && q < nvec && rank < maxp; q++) {
+            unsigned m = s_m8[q];
+            while (m && rank < maxp) {
+                const int j = __ffs(m) - 1;
+                m &= m - 1;
+                s_pk[rank++] = (q << 3) + j;
+            }
         }
     }
     __syncthreads();
+    stamp(stamps, wg, 2);
 
     // ---- A4: per-peak refinement, one wave per peak
     float4 *out = peaks + ((size_t)img * PP_NUM_PART + part) * maxp;
@@ -375,6 +455,8 @@ __global__ __launch_bounds__(kThreads) void k_heat_peaks(const T *__restrict__ n
         counts[img * PP_NUM_PART + part] = total;
         if (total > maxp) atomicOr(&status[img], PP_ST_PEAK_OVERFLOW);
     }
+    __syncthreads();
+    stamp(stamps, wg, 3);
 }
 
 // ------------------------------------------------------------------------------------------------ K_B
@@ -414,17 +496,27 @@ struct SortElem {
     float key;
     int gen;
 };
-struct StdSortGE {
+// element accessor: LDS arrays touched by one lane.  (A variant that kept the arrays in the VGPRs of one wave and
+// moved elements with v_readlane was measured 1.4x SLOWER: the extra instructions of a 4-register select cost more
+// issue slots on a lone wave than the LDS round trips they replace.)
+struct LdsSortAcc {
     float *key;
     int *gen;
-    int n;
-    bool oob;
-    __device__ __forceinline__ static bool ge(const SortElem &a, const SortElem &c) { return a.key >= c.key; }
     __device__ __forceinline__ SortElem get(int i) const { return SortElem{key[i], gen[i]}; }
-    __device__ __forceinline__ void put(int i, const SortElem &e) {
+    __device__ __forceinline__ void put(int i, const SortElem &e) const {
         key[i] = e.key;
         gen[i] = e.gen;
     }
+};
+template <typename Acc>
+struct StdSortGE {
+    Acc A;  // by value so that the register-resident form stays in registers
+    int n;
+    bool oob;
+    __device__ StdSortGE(const Acc &acc, int n_) : A(acc), n(n_), oob(false) {}
+    __device__ __forceinline__ static bool ge(const SortElem &a, const SortElem &c) { return a.key >= c.key; }
+    __device__ __forceinline__ SortElem get(int i) const { return A.get(i); }
+    __device__ __forceinline__ void put(int i, const SortElem &e) { A.put(i, e); }
     __device__ __forceinline__ void swp(int i, int j) {
         const SortElem t = get(i);
         put(i, get(j));
@@ -665,7 +757,7 @@ __device__ inline LimbLds carve_limb_lds(unsigned char *p, int maxp, int cap) {
 template <typename Sampler>
 __device__ void connect_limb(const Sampler &smp, const LimbLds &L, int nA, int nB, int cap, int maxp, int min_img_size,
                              float4 *__restrict__ conn_out, int *__restrict__ conn_count,
-                             unsigned *__restrict__ status_word) {
+                             unsigned *__restrict__ status_word, long long *stamps = nullptr, int wg = 0) {
     __shared__ int s_wcnt[2][kWaves];
     __shared__ int s_stack[3 * kSortStack];
     __shared__ int s_oob;
@@ -711,6 +803,7 @@ __device__ void connect_limb(const Sampler &smp, const LimbLds &L, int nA, int n
         ncand = cap;
     }
     const int n = ncand;
+    stamp(stamps, wg, 2);
     if (threadIdx.x == 0) s_oob = 0;
     for (int i = threadIdx.x; i < maxp; i += kThreads) {
         L.usedA[i] = 0;
@@ -742,10 +835,8 @@ __device__ void connect_limb(const Sampler &smp, const LimbLds &L, int nA, int n
         for (int t = threadIdx.x; t < n; t += kThreads) L.order[t] = t;
         __syncthreads();
         if (threadIdx.x == 0) {
-            StdSortGE srt;
-            srt.key = L.key;  // sorted in place: the generation-indexed copy is no longer needed
-            srt.gen = L.order;
-            srt.n = n;
+            LdsSortAcc acc{L.key, L.order};  // sorted in place: the generation-indexed keys are no longer needed
+            StdSortGE<LdsSortAcc> srt(acc, n);
             srt.run(s_stack);
             if (srt.oob) s_oob = 1;
         }
@@ -757,6 +848,7 @@ __device__ void connect_limb(const Sampler &smp, const LimbLds &L, int nA, int n
     __syncthreads();
     if (s_oob) st |= PP_ST_SORT_UNDEFINED;
 
+    stamp(stamps, wg, 3);
     // ---- 3. greedy matching by local dominance
     while (true) {
         for (int i = threadIdx.x; i < maxp; i += kThreads) {
@@ -794,6 +886,7 @@ __device__ void connect_limb(const Sampler &smp, const LimbLds &L, int nA, int n
         __syncthreads();
     }
 
+    stamp(stamps, wg, 4);
     // ---- 4. ordered output
     int ncn = 0;
     for (int base = 0; base < n; base += kThreads, buf ^= 1) {
@@ -825,6 +918,7 @@ __device__ void connect_limb(const Sampler &smp, const LimbLds &L, int nA, int n
         *conn_count = ncn;
         if (st) atomicOr(status_word, st);
     }
+    stamp(stamps, wg, 5);
 }
 
 // LDS layout (dynamic): [map h*w T][cubic 16 f32][LimbLds: 40*maxp + 28*cap bytes]
@@ -872,12 +966,17 @@ __global__ __launch_bounds__(kThreads) void k_limb_connect(const T *__restrict__
     const size_t plane = (size_t)npix;
     const T *o0 = net + ((size_t)img * n_samples * PP_NUM_CH + limb) * plane;
     const T *o1 = net + (((size_t)img * n_samples + 1) * PP_NUM_CH + d_flip_paf_ord[limb]) * plane;
+    long long *stamps = d_stamps;
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    stamp(stamps, wg, 0);
     load_channel(smap, o0, o1, h, w, flip != 0);
     __syncthreads();
+    stamp(stamps, wg, 1);
 
     LdsBicubicSampler<T> smp{smap, s_cub, h, w};
     const int mis = min_img_size_dev ? min_img_size_dev[img] : min_img_size;
-    connect_limb(smp, L, nA, nB, cap, maxp, mis, conns + ((size_t)img * PP_NUM_LIMB + limb) * maxp, cc, status + img);
+    connect_limb(smp, L, nA, nB, cap, maxp, mis, conns + ((size_t)img * PP_NUM_LIMB + limb) * maxp, cc, status + img,
+                 stamps, wg);
 }
 
 // Drop-in path: the caller's (H, W, C) up-sampled map lives in global memory (uploaded by process_paf)
@@ -1160,8 +1259,8 @@ __global__ __launch_bounds__(64) void k_assemble(int maxp, int explicit_ids, con
 
 // ------------------------------------------------------------------------------------------------ launchers
 size_t lds_bytes_heat(int elem, int h, int w, int maxp) {
-    const size_t npix = (size_t)h * w, nchunks = (npix + 63) / 64;
-    return ((elem * npix + 15) & ~(size_t)15) + 64 + 8 * nchunks + 4 * (nchunks + 4) + 4 * (size_t)maxp;
+    const size_t npix = (size_t)h * w;
+    return ((elem * npix + 15) & ~(size_t)15) + 64 + ((4 * (size_t)maxp + 15) & ~(size_t)15) + ((npix + 7) / 8 + 15) / 16 * 16;
 }
 size_t lds_bytes_limb(int elem, int h, int w, int maxp, int cap) {
     const size_t npix = (size_t)h * w;
@@ -1172,6 +1271,10 @@ size_t lds_bytes_assemble(int maxp) { return assemble_lds_bytes(maxp); }
 
 // Dynamic LDS above the 64 KB default needs the attribute; set once per process (pp_create), not per launch, so
 // that the per-batch entry points stay free of anything but kernel launches (hipGraph-capturable).
+hipError_t set_stamp_buffer(long long *buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(d_stamps), &buf, sizeof(buf));
+}
+
 hipError_t init_kernel_attributes() {
     const int lim = (int)kMaxDynLds;
     const void *fns[] = {reinterpret_cast<const void *>(&k_heat_peaks<__half>),

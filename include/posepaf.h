@@ -121,6 +121,10 @@ PP_API int pp_time_kernels(pp_ctx *ctx, int batch, const void *net_out_dev, int 
 PP_API int pp_bias_act_f16(void *y, const void *bias, const void *residual, long n_elems, int channels, float slope,
                            int has_act, void *stream);
 
+/* Diagnostics: register a DEVICE buffer of 8 int64 per workgroup; K_A and K_B then store shader-clock stamps at
+ * their phase boundaries (slot 0 start, 1 map in LDS, ...).  NULL (default) disables it. */
+PP_API int pp_debug_set_stamps(long long *stamps_dev);
+
 /* Blocking read-backs of the context's workspace for the last batch (host pointers).
  * pp_read_peaks: joint_list rows [x, y, score, peak_id, part] (evaluate.py:99-103) of one image. */
 PP_API int pp_read_peaks(pp_ctx *ctx, int image, float *joint_list_host, int max_rows, int *n_rows);
