@@ -11,18 +11,23 @@
 
 namespace {
 
-template <bool HAS_RES, bool HAS_ACT>
+// y = act(y + bias[c] (+ res)) (+ post)      res is added BEFORE the activation (residual blocks), post AFTER it
+// (hourglass: up1 + conv(upsample(..)))
+template <bool HAS_RES, bool HAS_ACT, bool HAS_POST>
 __global__ __launch_bounds__(256) void k_bias_act(uint4 *__restrict__ y, const uint4 *__restrict__ bias,
-                                                  const uint4 *__restrict__ res, long nvec, int cvec, float slope) {
+                                                  const uint4 *__restrict__ res, const uint4 *__restrict__ post, long nvec,
+                                                  int cvec, float slope) {
     const long stride = (long)gridDim.x * blockDim.x;
     for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
         uint4 a = y[v];
         const uint4 b = bias[v % cvec];
-        uint4 r;
+        uint4 r, p;
         if (HAS_RES) r = res[v];
+        if (HAS_POST) p = post[v];
         __half2 *ah = reinterpret_cast<__half2 *>(&a);
         const __half2 *bh = reinterpret_cast<const __half2 *>(&b);
         const __half2 *rh = reinterpret_cast<const __half2 *>(&r);
+        const __half2 *ph = reinterpret_cast<const __half2 *>(&p);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             float2 f = __half22float2(ah[k]);
@@ -38,33 +43,118 @@ __global__ __launch_bounds__(256) void k_bias_act(uint4 *__restrict__ y, const u
                 f.x = f.x > 0.f ? f.x : f.x * slope;
                 f.y = f.y > 0.f ? f.y : f.y * slope;
             }
+            if (HAS_POST) {
+                const float2 fp = __half22float2(ph[k]);
+                f.x += fp.x;
+                f.y += fp.y;
+            }
             ah[k] = __float22half2_rn(f);
         }
         y[v] = a;
     }
 }
 
+// 2x2/2 max pool and x2 nearest upsample on NHWC fp16, 8 channels (16 bytes) per lane, coalesced along C.
+__global__ __launch_bounds__(256) void k_maxpool2(const uint4 *__restrict__ x, uint4 *__restrict__ y, long nvec_out, int Ho,
+                                                  int Wo, int cvec) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    const int W = Wo * 2;
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec_out; v += stride) {
+        const int c = (int)(v % cvec);
+        long t = v / cvec;
+        const int wo = (int)(t % Wo);
+        t /= Wo;
+        const int ho = (int)(t % Ho);
+        const long n = t / Ho;
+        const long base = ((n * (Ho * 2) + ho * 2) * W + wo * 2) * cvec + c;
+        const uint4 a = x[base], b = x[base + cvec], cc = x[base + (long)W * cvec], d = x[base + (long)W * cvec + cvec];
+        uint4 o;
+        const __half2 *ah = reinterpret_cast<const __half2 *>(&a), *bh = reinterpret_cast<const __half2 *>(&b);
+        const __half2 *ch = reinterpret_cast<const __half2 *>(&cc), *dh = reinterpret_cast<const __half2 *>(&d);
+        __half2 *oh = reinterpret_cast<__half2 *>(&o);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float2 fa = __half22float2(ah[k]), fb = __half22float2(bh[k]);
+            const float2 fc = __half22float2(ch[k]), fd = __half22float2(dh[k]);
+            oh[k] = __float22half2_rn(make_float2(fmaxf(fmaxf(fa.x, fb.x), fmaxf(fc.x, fd.x)),
+                                                  fmaxf(fmaxf(fa.y, fb.y), fmaxf(fc.y, fd.y))));
+        }
+        y[v] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_upsample2(const uint4 *__restrict__ x, uint4 *__restrict__ y, long nvec_in, int Hi,
+                                                   int Wi, int cvec) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    const int W = Wi * 2;
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec_in; v += stride) {
+        const int c = (int)(v % cvec);
+        long t = v / cvec;
+        const int wi = (int)(t % Wi);
+        t /= Wi;
+        const int hi = (int)(t % Hi);
+        const long n = t / Hi;
+        const uint4 a = x[v];
+        const long base = ((n * (Hi * 2) + hi * 2) * W + wi * 2) * cvec + c;
+        y[base] = a;
+        y[base + cvec] = a;
+        y[base + (long)W * cvec] = a;
+        y[base + (long)W * cvec + cvec] = a;
+    }
+}
+
+inline long grid_for(long nvec) {
+    long blocks = (nvec + 255) / 256;
+    return blocks > 8192 ? 8192 : blocks;
+}
+
 }  // namespace
 
-extern "C" int pp_bias_act_f16(void *y, const void *bias, const void *residual, long n_elems, int channels, float slope,
-                               int has_act, void *stream) {
+extern "C" int pp_bias_act_f16(void *y, const void *bias, const void *residual, const void *post, long n_elems,
+                               int channels, float slope, int has_act, void *stream) {
     if (!y || !bias || n_elems <= 0 || channels <= 0 || (channels & 7) || (n_elems % channels) ||
         (reinterpret_cast<uintptr_t>(y) & 15) || (reinterpret_cast<uintptr_t>(bias) & 15) ||
-        (reinterpret_cast<uintptr_t>(residual) & 15))
+        (reinterpret_cast<uintptr_t>(residual) & 15) || (reinterpret_cast<uintptr_t>(post) & 15))
         return PP_ERR_BAD_ARG;
     const long nvec = n_elems / 8;
     const int cvec = channels / 8;
-    long blocks = (nvec + 255) / 256;
-    if (blocks > 2048 * 4) blocks = 2048 * 4;  // grid-stride beyond 8 blocks per CU x 4
+    const dim3 grid(grid_for(nvec)), block(256);
     hipStream_t st = static_cast<hipStream_t>(stream);
     uint4 *yy = static_cast<uint4 *>(y);
     const uint4 *bb = static_cast<const uint4 *>(bias), *rr = static_cast<const uint4 *>(residual);
-    if (residual) {
-        if (has_act) hipLaunchKernelGGL((k_bias_act<true, true>), dim3(blocks), dim3(256), 0, st, yy, bb, rr, nvec, cvec, slope);
-        else hipLaunchKernelGGL((k_bias_act<true, false>), dim3(blocks), dim3(256), 0, st, yy, bb, rr, nvec, cvec, slope);
-    } else {
-        if (has_act) hipLaunchKernelGGL((k_bias_act<false, true>), dim3(blocks), dim3(256), 0, st, yy, bb, rr, nvec, cvec, slope);
-        else hipLaunchKernelGGL((k_bias_act<false, false>), dim3(blocks), dim3(256), 0, st, yy, bb, rr, nvec, cvec, slope);
+    const uint4 *pp = static_cast<const uint4 *>(post);
+#define PP_LAUNCH(R, A, P) hipLaunchKernelGGL((k_bias_act<R, A, P>), grid, block, 0, st, yy, bb, rr, pp, nvec, cvec, slope)
+    const int sel = (residual ? 4 : 0) | (has_act ? 2 : 0) | (post ? 1 : 0);
+    switch (sel) {
+        case 0: PP_LAUNCH(false, false, false); break;
+        case 1: PP_LAUNCH(false, false, true); break;
+        case 2: PP_LAUNCH(false, true, false); break;
+        case 3: PP_LAUNCH(false, true, true); break;
+        case 4: PP_LAUNCH(true, false, false); break;
+        case 5: PP_LAUNCH(true, false, true); break;
+        case 6: PP_LAUNCH(true, true, false); break;
+        default: PP_LAUNCH(true, true, true); break;
     }
+#undef PP_LAUNCH
+    return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
+}
+
+extern "C" int pp_maxpool2_f16(const void *x, void *y, long n, int h_out, int w_out, int channels, void *stream) {
+    if (!x || !y || n <= 0 || h_out <= 0 || w_out <= 0 || channels <= 0 || (channels & 7) ||
+        (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15))
+        return PP_ERR_BAD_ARG;
+    const long nvec = n * h_out * w_out * (channels / 8);
+    hipLaunchKernelGGL(k_maxpool2, dim3(grid_for(nvec)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const uint4 *>(x), static_cast<uint4 *>(y), nvec, h_out, w_out, channels / 8);
+    return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
+}
+
+extern "C" int pp_upsample2_f16(const void *x, void *y, long n, int h_in, int w_in, int channels, void *stream) {
+    if (!x || !y || n <= 0 || h_in <= 0 || w_in <= 0 || channels <= 0 || (channels & 7) ||
+        (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15))
+        return PP_ERR_BAD_ARG;
+    const long nvec = n * h_in * w_in * (channels / 8);
+    hipLaunchKernelGGL(k_upsample2, dim3(grid_for(nvec)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const uint4 *>(x), static_cast<uint4 *>(y), nvec, h_in, w_in, channels / 8);
     return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
 }

@@ -20,19 +20,53 @@ from torch import nn
 LEAK = 0.01
 
 
-def hip_bias_act_(y: torch.Tensor, bias: torch.Tensor, res, act: bool) -> torch.Tensor:
-    """In place y = act(y + bias[c] (+ res)) by the fused HIP epilogue kernel (csrc/posepaf_epilogue.hip)."""
+def _cl(t):
+    return t if t.is_contiguous(memory_format=torch.channels_last) else t.contiguous(memory_format=torch.channels_last)
+
+
+def _ptr(t):
     import ctypes as C
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream(t):
+    import ctypes as C
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def hip_bias_act_(y: torch.Tensor, bias: torch.Tensor, res, act: bool, post=None) -> torch.Tensor:
+    """In place y = act(y + bias[c] (+ res)) (+ post) by the fused HIP epilogue kernel (csrc/posepaf_epilogue.hip)."""
     from . import _lib
-    if not y.is_contiguous(memory_format=torch.channels_last):
-        y = y.contiguous(memory_format=torch.channels_last)
-    if res is not None and not res.is_contiguous(memory_format=torch.channels_last):
-        res = res.contiguous(memory_format=torch.channels_last)
-    L = _lib.load()
-    rc = L.pp_bias_act_f16(C.c_void_p(y.data_ptr()), C.c_void_p(bias.data_ptr()),
-                           C.c_void_p(res.data_ptr()) if res is not None else None, y.numel(), y.shape[1], LEAK, int(act),
-                           C.c_void_p(torch.cuda.current_stream(y.device).cuda_stream))
+    y = _cl(y)
+    res = _cl(res) if res is not None else None
+    post = _cl(post) if post is not None else None
+    rc = _lib.load().pp_bias_act_f16(_ptr(y), _ptr(bias), _ptr(res), _ptr(post), y.numel(), y.shape[1], LEAK, int(act),
+                                     _stream(y))
     _lib.check(rc)
+    return y
+
+
+def maxpool2(x: torch.Tensor) -> torch.Tensor:
+    """2x2/2 max pool; HIP kernel on channels-last fp16, torch elsewhere."""
+    n, c, h, w = x.shape
+    if not (x.is_cuda and x.dtype == torch.float16 and c % 8 == 0 and h % 2 == 0 and w % 2 == 0):
+        return F.max_pool2d(x, 2, 2)
+    from . import _lib
+    x = _cl(x)
+    y = torch.empty((n, c, h // 2, w // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    _lib.check(_lib.load().pp_maxpool2_f16(_ptr(x), _ptr(y), n, h // 2, w // 2, c, _stream(x)))
+    return y
+
+
+def upsample2(x: torch.Tensor) -> torch.Tensor:
+    """nearest x2 upsample; HIP kernel on channels-last fp16, torch elsewhere."""
+    n, c, h, w = x.shape
+    if not (x.is_cuda and x.dtype == torch.float16 and c % 8 == 0):
+        return F.interpolate(x, scale_factor=2, mode="nearest")
+    from . import _lib
+    x = _cl(x)
+    y = torch.empty((n, c, h * 2, w * 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    _lib.check(_lib.load().pp_upsample2_f16(_ptr(x), _ptr(y), n, h, w, c, _stream(x)))
     return y
 
 
@@ -64,14 +98,16 @@ class FConv(nn.Module):
     def conv_only(self, x):
         return F.conv2d(x, self.weight, None, self.stride, self.padding, self.dilation)
 
-    def forward(self, x, res=None):
-        """act(conv(x) + bias (+ res))"""
+    def forward(self, x, res=None, post=None):
+        """act(conv(x) + bias (+ res)) (+ post)"""
         if _use_hip(x, self.weight.shape[0]):
-            return hip_bias_act_(self.conv_only(x), self.bias, res, self.act)
+            return hip_bias_act_(self.conv_only(x), self.bias, res, self.act, post)
         y = F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation)
         if res is not None:
             y = y + res
-        return F.leaky_relu_(y, LEAK) if self.act else y
+        if self.act:
+            y = F.leaky_relu_(y, LEAK)
+        return y + post if post is not None else y
 
 
 def _fconv_from_block(m, act=None):  # models.layers_transposed.Conv / DilatedConv
@@ -109,11 +145,10 @@ class FHourglass(nn.Module):
     def _level(self, i, x, coarse):
         lv = self.levels[i]
         up1 = lv[0](x)
-        low = lv[1](F.max_pool2d(x, 2, 2))
+        low = lv[1](maxpool2(x))
         low = lv[4](low) if i == self.depth - 1 else self._level(i + 1, low, coarse)
         coarse.append(low)
-        up2 = F.interpolate(lv[2](low), scale_factor=2, mode="nearest")
-        return up1 + lv[3](up2)
+        return lv[3](upsample2(lv[2](low)), post=up1)  # up1 + act(conv(up2) + b): the add rides on the epilogue
 
     def forward(self, x):
         coarse = []
@@ -169,7 +204,7 @@ class FusedIMHN(nn.Module):
     def forward(self, imgs):
         x = imgs.permute(0, 3, 1, 2)  # NHWC storage viewed as NCHW == channels_last: no copy
         x = self.stem(x)
-        x = self.res2(F.max_pool2d(self.res1(x), 2, 2))
+        x = self.res2(maxpool2(self.res1(x)))
         d = x
         for m in self.dil:
             d = m(d)

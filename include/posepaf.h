@@ -115,11 +115,16 @@ PP_API int pp_nms_batch(pp_ctx *ctx, int batch, const void *net_out_dev, int dty
 PP_API int pp_time_kernels(pp_ctx *ctx, int batch, const void *net_out_dev, int dtype, int h, int w, int flip,
                            int min_img_size, int iters, float *ms_out, void *stream);
 
-/* Forward-pass helper (not part of the reference's interface): fused convolution epilogue on a channels-last
- * (NHWC) fp16 activation, in place: y = act(y + bias[c] (+ residual)), act = LeakyReLU(slope) if has_act.
- * y/residual: DEVICE fp16, n_elems = N*H*W*C, channels % 8 == 0, 16-byte aligned; bias: DEVICE fp16[channels]. */
-PP_API int pp_bias_act_f16(void *y, const void *bias, const void *residual, long n_elems, int channels, float slope,
-                           int has_act, void *stream);
+/* Forward-pass helpers (not part of the reference's interface), all on channels-last (NHWC) fp16 DEVICE tensors with
+ * channels % 8 == 0 and 16-byte aligned pointers:
+ *   pp_bias_act_f16 : in place  y = act(y + bias[c] (+ residual)) (+ post),  act = LeakyReLU(slope) if has_act;
+ *                     n_elems = N*H*W*C; bias fp16[channels]; residual / post may be NULL
+ *   pp_maxpool2_f16 : y[n][ho][wo][c] = max of the 2x2 window of x (x is (n, 2*h_out, 2*w_out, c))
+ *   pp_upsample2_f16: nearest x2: y (n, 2*h_in, 2*w_in, c) from x (n, h_in, w_in, c) */
+PP_API int pp_bias_act_f16(void *y, const void *bias, const void *residual, const void *post, long n_elems, int channels,
+                           float slope, int has_act, void *stream);
+PP_API int pp_maxpool2_f16(const void *x, void *y, long n, int h_out, int w_out, int channels, void *stream);
+PP_API int pp_upsample2_f16(const void *x, void *y, long n, int h_in, int w_in, int channels, void *stream);
 
 /* Diagnostics: register a DEVICE buffer of 8 int64 per workgroup; K_A and K_B then store shader-clock stamps at
  * their phase boundaries (slot 0 start, 1 map in LDS, ...).  NULL (default) disables it. */
