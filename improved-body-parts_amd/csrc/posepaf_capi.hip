@@ -227,7 +227,9 @@ int pp_read_peaks(pp_ctx *ctx, int image, float *joint_list_host, int max_rows, 
     PP_HIP(ctx, hipMemcpy(pk.data(), ctx->last_peaks + (size_t)image * PP_NUM_PART * ctx->maxp, pk.size() * sizeof(float4),
                           hipMemcpyDeviceToHost));
     int n = 0;
+    bool truncated = false;
     for (int part = 0; part < PP_NUM_PART; part++) {
+        if (counts[part] > ctx->maxp) truncated = true;
         const int c = counts[part] < ctx->maxp ? counts[part] : ctx->maxp;
         for (int r = 0; r < c; r++, n++) {
             if (joint_list_host && n < max_rows) {
@@ -242,7 +244,7 @@ int pp_read_peaks(pp_ctx *ctx, int image, float *joint_list_host, int max_rows, 
         }
     }
     *n_rows = n;
-    return PP_OK;
+    return truncated ? PP_ERR_OVERFLOW : PP_OK;  // rows are valid but a part had more peaks than the context holds
 }
 
 int pp_read_connections(pp_ctx *ctx, int image, int limb, float *rows_host, int max_rows, int *n_rows) {

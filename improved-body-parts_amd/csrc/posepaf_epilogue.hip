@@ -158,3 +158,119 @@ extern "C" int pp_upsample2_f16(const void *x, void *y, long n, int h_in, int w_
                        static_cast<const uint4 *>(x), static_cast<uint4 *>(y), nvec, h_in, w_in, channels / 8);
     return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
 }
+
+// ------------------------------------------------------------------------------------------------ A0 pre-processing
+// utils/parse_skeletons.py:52-73 + utils/util.py:44-65 for a batch of equally sized BGR uint8 images (scale 1):
+// pad bottom/right to a multiple of `pad_to` with `pad_value`, x / 255 -> float, and emit each image followed by the
+// W-mirror of the PADDED image (the reference flips after padding, so the mirror's padding sits on the left).
+// out: (2B or B, Hp, Wp, 3) NHWC, fp16 or fp32.  One thread per output pixel of the un-mirrored sample.
+namespace {
+template <typename OutT>
+__device__ __forceinline__ OutT cvt_out(float v);
+template <>
+__device__ __forceinline__ float cvt_out<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ __half cvt_out<__half>(float v) { return __float2half(v); }
+
+template <typename OutT>
+__global__ __launch_bounds__(256) void k_preprocess(const unsigned char *__restrict__ img, OutT *__restrict__ out, int B,
+                                                    int H, int W, int Hp, int Wp, int flip, float pad_norm) {
+    const long npix = (long)B * Hp * Wp;
+    const long stride = (long)gridDim.x * blockDim.x;
+    const int ns = flip ? 2 : 1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += stride) {
+        const int x = (int)(i % Wp);
+        long t = i / Wp;
+        const int y = (int)(t % Hp);
+        const long b = t / Hp;
+        float v[3];
+        if (y < H && x < W) {
+            const unsigned char *p = img + ((b * H + y) * W + x) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; c++) v[c] = (float)p[c] / 255.0f;  // == np.float32(u8 / 255): checked for all 256 values
+        } else {
+            v[0] = v[1] = v[2] = pad_norm;
+        }
+        OutT *o0 = out + (((b * ns) * Hp + y) * Wp + x) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; c++) o0[c] = cvt_out<OutT>(v[c]);
+        if (flip) {
+            OutT *o1 = out + (((b * ns + 1) * Hp + y) * Wp + (Wp - 1 - x)) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; c++) o1[c] = cvt_out<OutT>(v[c]);
+        }
+    }
+}
+}  // namespace
+
+extern "C" int pp_preprocess_u8(const void *images_u8, void *out, int dtype, int batch, int h, int w, int pad_to,
+                                int pad_value, int flip, void *stream) {
+    if (!images_u8 || !out || batch <= 0 || h <= 0 || w <= 0 || pad_to <= 0 || (dtype != PP_F16 && dtype != PP_F32))
+        return PP_ERR_BAD_ARG;
+    const int Hp = (h + pad_to - 1) / pad_to * pad_to, Wp = (w + pad_to - 1) / pad_to * pad_to;
+    const long npix = (long)batch * Hp * Wp;
+    const dim3 grid(grid_for((npix + 0) / 1)), block(256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float pad_norm = (float)pad_value / 255.0f;
+    if (dtype == PP_F16)
+        hipLaunchKernelGGL(k_preprocess<__half>, grid, block, 0, st, static_cast<const unsigned char *>(images_u8),
+                           static_cast<__half *>(out), batch, h, w, Hp, Wp, flip, pad_norm);
+    else
+        hipLaunchKernelGGL(k_preprocess<float>, grid, block, 0, st, static_cast<const unsigned char *>(images_u8),
+                           static_cast<float *>(out), batch, h, w, Hp, Wp, flip, pad_norm);
+    return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
+}
+
+// ------------------------------------------------------------------------------------------------ A2 standalone
+// predict_refactor's return value (utils/parse_skeletons.py:82-103): heat (h, w, 20) and paf (h, w, 30), HWC float32,
+// flip-averaged in the input's dtype.  The fused kernels K_A/K_B never materialise these; this entry point exists for
+// callers that want the reference's intermediate arrays.  One thread per (y, x, c).
+namespace {
+__device__ const signed char e_flip_heat[PP_NUM_HEAT] = {0, 1, 5, 6, 7, 2, 3, 4, 11, 12, 13, 8, 9, 10, 15, 14, 17, 16, 18, 19};
+__device__ const signed char e_flip_paf[PP_NUM_LIMB] = {0,  2,  1,  4,  3,  6,  5,  8,  7,  12, 13, 14, 9,  10, 11,
+                                                       18, 19, 20, 15, 16, 17, 22, 21, 25, 26, 23, 24, 28, 27, 29};
+__device__ __forceinline__ float avg_elem(const __half *p, long i0, long i1, bool flip) {
+    return flip ? __half2float(__hmul(__hadd(p[i0], p[i1]), __float2half(0.5f))) : __half2float(p[i0]);
+}
+__device__ __forceinline__ float avg_elem(const float *p, long i0, long i1, bool flip) {
+    return flip ? __fadd_rn(p[i0], p[i1]) / 2.0f : p[i0];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_flip_average(const T *__restrict__ net, int batch, int h, int w, int flip,
+                                                      float *__restrict__ heat, float *__restrict__ paf) {
+    const long plane = (long)h * w;
+    const long total = (long)batch * plane * PP_NUM_CH;
+    const long stride = (long)gridDim.x * blockDim.x;
+    const int ns = flip ? 2 : 1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int c = (int)(i % PP_NUM_CH);
+        long t = i / PP_NUM_CH;
+        const int x = (int)(t % w);
+        t /= w;
+        const int y = (int)(t % h);
+        const long b = t / h;
+        const int cf = c < PP_NUM_LIMB ? e_flip_paf[c] : PP_NUM_LIMB + e_flip_heat[c - PP_NUM_LIMB];
+        const long i0 = ((b * ns) * PP_NUM_CH + c) * plane + (long)y * w + x;
+        const long i1 = ((b * ns + 1) * PP_NUM_CH + cf) * plane + (long)y * w + (w - 1 - x);
+        const float v = avg_elem(net, i0, i1, flip != 0);
+        if (c < PP_NUM_LIMB) paf[((b * h + y) * w + x) * PP_NUM_LIMB + c] = v;
+        else heat[((b * h + y) * w + x) * PP_NUM_HEAT + (c - PP_NUM_LIMB)] = v;
+    }
+}
+}  // namespace
+
+extern "C" int pp_flip_average(const void *net_out_dev, int dtype, int batch, int h, int w, int flip, float *heat_hwc_dev,
+                               float *paf_hwc_dev, void *stream) {
+    if (!net_out_dev || !heat_hwc_dev || !paf_hwc_dev || batch <= 0 || h <= 0 || w <= 0 || (dtype != PP_F16 && dtype != PP_F32))
+        return PP_ERR_BAD_ARG;
+    const long total = (long)batch * h * w * PP_NUM_CH;
+    const dim3 grid(grid_for(total)), block(256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == PP_F16)
+        hipLaunchKernelGGL(k_flip_average<__half>, grid, block, 0, st, static_cast<const __half *>(net_out_dev), batch, h, w,
+                           flip, heat_hwc_dev, paf_hwc_dev);
+    else
+        hipLaunchKernelGGL(k_flip_average<float>, grid, block, 0, st, static_cast<const float *>(net_out_dev), batch, h, w,
+                           flip, heat_hwc_dev, paf_hwc_dev);
+    return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
+}

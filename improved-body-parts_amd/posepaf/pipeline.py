@@ -13,15 +13,33 @@ from . import skeleton as sk
 from .api import PosePostProcessor, records_to_numpy
 
 
-def preprocess_batch(images_u8: torch.Tensor, flip: bool = True) -> torch.Tensor:
-    """utils/parse_skeletons.py:52-73 for a batch of equally sized images already padded to a multiple of 64:
-    uint8 BGR (B,H,W,3) -> float32 NHWC in [0,1], each image followed by its W-mirrored copy -> (2B,H,W,3).
+def preprocess_batch(images_u8: torch.Tensor, flip: bool = True, dtype=torch.float32) -> torch.Tensor:
+    """utils/parse_skeletons.py:52-73 + utils/util.py:44-65 for a batch of equally sized images (scale 1):
+    uint8 BGR (B,H,W,3) -> pad bottom/right to a multiple of 64 with 128 -> /255 -> NHWC in [0,1], each image followed
+    by the W-mirror of the padded image -> (2B,Hp,Wp,3).  One HIP kernel (pp_preprocess_u8) on the GPU.
     `np.float32(img / 255)` is a float64 division rounded to float32; float32(x)/255 in float32 is the same
     correctly rounded quotient for every x in 0..255 (checked exhaustively in tests/test_pipeline_cpu.py)."""
-    x = images_u8.to(torch.float32) / 255.0
+    B, H, W, _ = images_u8.shape
+    Hp = -(-H // sk.MAX_DOWNSAMPLE) * sk.MAX_DOWNSAMPLE
+    Wp = -(-W // sk.MAX_DOWNSAMPLE) * sk.MAX_DOWNSAMPLE
+    if images_u8.is_cuda and dtype in (torch.float16, torch.float32):
+        import ctypes as C
+        from . import _lib
+        images_u8 = images_u8.contiguous()
+        out = torch.empty((B * (2 if flip else 1), Hp, Wp, 3), dtype=dtype, device=images_u8.device)
+        rc = _lib.load().pp_preprocess_u8(C.c_void_p(images_u8.data_ptr()), C.c_void_p(out.data_ptr()),
+                                          _lib.PP_F16 if dtype == torch.float16 else _lib.PP_F32, B, H, W, sk.MAX_DOWNSAMPLE,
+                                          sk.PAD_VALUE, int(flip),
+                                          C.c_void_p(torch.cuda.current_stream(images_u8.device).cuda_stream))
+        _lib.check(rc)
+        return out
+    # host tensors (unit tests of the formula only)
+    x = torch.full((B, Hp, Wp, 3), float(sk.PAD_VALUE), dtype=torch.float32)
+    x[:, :H, :W] = images_u8.to(torch.float32)
+    x = (x / 255.0).to(dtype)
     if not flip:
         return x
-    return torch.stack((x, x.flip(2)), dim=1).reshape(-1, *x.shape[1:])
+    return torch.stack((x, x.flip(2)), dim=1).reshape(-1, Hp, Wp, 3)
 
 
 class PosePipeline:
@@ -34,7 +52,7 @@ class PosePipeline:
     @torch.no_grad()
     def forward_maps(self, images_u8: torch.Tensor) -> torch.Tensor:
         """-> (B, 2|1, 50, H/4, W/4) last-stage scale-0 output (utils/parse_skeletons.py:76-80 `[-1][0]`)."""
-        x = preprocess_batch(images_u8, self.flip).to(self.dtype)
+        x = preprocess_batch(images_u8, self.flip, self.dtype)
         out = self.model(x)
         maps = out[-1][0] if isinstance(out, (list, tuple)) else out
         ns = 2 if self.flip else 1

@@ -1,0 +1,37 @@
+"""Helpers with the reference's names (utils/util.py): padRightDownCorner (:44-65), keypoint_heatmap_nms (:177-185),
+refine_centroid (:188-213).  Colour-map / Gaussian-smoothing utilities of that file are visualisation and out of scope."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def padRightDownCorner(img, stride, padValue):
+    """Pad bottom/right so that H and W become multiples of `stride`; returns (padded, [up, left, down, right])."""
+    h, w = img.shape[0], img.shape[1]
+    pad = [0, 0, 0 if h % stride == 0 else stride - (h % stride), 0 if w % stride == 0 else stride - (w % stride)]
+    out = np.full((h + pad[2], w + pad[3]) + img.shape[2:], padValue, dtype=img.dtype)
+    out[:h, :w] = img
+    return out, pad
+
+
+def keypoint_heatmap_nms(heat, kernel=3, thre=0.1):
+    """3x3 max-pool NMS on a (1, C, H, W) tensor (stays on the tensor's device): keep heat where it equals the
+    reflect-padded window maximum and is >= thre."""
+    pad = (kernel - 1) // 2
+    hmax = F.max_pool2d(F.pad(heat, (pad, pad, pad, pad), mode="reflect"), (kernel, kernel), stride=1, padding=0)
+    keep = (hmax == heat).float() * (heat >= thre).float()
+    return heat * keep
+
+
+def refine_centroid(scorefmp, anchor, radius):
+    """(2r+1)^2 weighted centroid around an integer peak; border peaks are returned unrefined with the raw score,
+    otherwise the score is the box MEAN (utils/util.py:200-213, including its row/column grid convention)."""
+    x_c, y_c = anchor
+    x_min, x_max, y_min, y_max = x_c - radius, x_c + radius + 1, y_c - radius, y_c + radius + 1
+    if y_max > scorefmp.shape[0] or y_min < 0 or x_max > scorefmp.shape[1] or x_min < 0:
+        return anchor + (scorefmp[y_c, x_c],)
+    box = scorefmp[y_min:y_max, x_min:x_max]
+    x_grid, y_grid = np.mgrid[-radius:radius + 1, -radius:radius + 1]
+    offset_x = (box * x_grid).sum() / box.sum()
+    offset_y = (box * y_grid).sum() / box.sum()
+    return (x_c + offset_x, y_c + offset_y) + (box.mean(),)

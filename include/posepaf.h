@@ -126,12 +126,24 @@ PP_API int pp_bias_act_f16(void *y, const void *bias, const void *residual, cons
 PP_API int pp_maxpool2_f16(const void *x, void *y, long n, int h_out, int w_out, int channels, void *stream);
 PP_API int pp_upsample2_f16(const void *x, void *y, long n, int h_in, int w_in, int channels, void *stream);
 
+/* A0 pre-processing (utils/parse_skeletons.py:52-73, utils/util.py:44-65) of a batch of equally sized BGR uint8 DEVICE
+ * images (batch, h, w, 3): pad bottom/right to a multiple of pad_to with pad_value, divide by 255, and write each image
+ * followed (flip != 0) by the W-mirror of the PADDED image.  out: DEVICE (batch*(flip?2:1), Hp, Wp, 3), PP_F16 or PP_F32. */
+PP_API int pp_preprocess_u8(const void *images_u8, void *out, int dtype, int batch, int h, int w, int pad_to,
+                            int pad_value, int flip, void *stream);
+
+/* A2 standalone: the arrays predict_refactor returns (utils/parse_skeletons.py:82-103).  net_out_dev as for
+ * pp_process_batch; heat_hwc_dev: DEVICE float[batch][h][w][20], paf_hwc_dev: DEVICE float[batch][h][w][30]. */
+PP_API int pp_flip_average(const void *net_out_dev, int dtype, int batch, int h, int w, int flip, float *heat_hwc_dev,
+                           float *paf_hwc_dev, void *stream);
+
 /* Diagnostics: register a DEVICE buffer of 8 int64 per workgroup; K_A and K_B then store shader-clock stamps at
  * their phase boundaries (slot 0 start, 1 map in LDS, ...).  NULL (default) disables it. */
 PP_API int pp_debug_set_stamps(long long *stamps_dev);
 
 /* Blocking read-backs of the context's workspace for the last batch (host pointers).
- * pp_read_peaks: joint_list rows [x, y, score, peak_id, part] (evaluate.py:99-103) of one image. */
+ * pp_read_peaks: joint_list rows [x, y, score, peak_id, part] (evaluate.py:99-103) of one image; returns
+ * PP_ERR_OVERFLOW (rows still filled, truncated per part) when a part had more peaks than max_peaks_per_part. */
 PP_API int pp_read_peaks(pp_ctx *ctx, int image, float *joint_list_host, int max_rows, int *n_rows);
 /* connections of one limb of one image, rows {cid1, cid2, score, length} (pafprocess.h:60-67) */
 PP_API int pp_read_connections(pp_ctx *ctx, int image, int limb, float *rows_host, int max_rows, int *n_rows);

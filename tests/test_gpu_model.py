@@ -68,3 +68,16 @@ def test_pipeline_end_to_end_runs():
     assert ((rec["n_humans"] >= 0) & (rec["n_humans"] <= 128)).all()
     r = pipe(img)
     assert r.shape == (2,)
+
+
+@pytest.mark.parametrize("shape", [(37, 70), (512, 512), (480, 640)])
+def test_preprocess_kernel_matches_host_formula(shape):
+    """pp_preprocess_u8 (A0) == the reference's pad / 255 / flip expression, fp32 exactly and fp16 after rounding."""
+    from posepaf.pipeline import preprocess_batch
+    h, w = shape
+    img = torch.from_numpy(np.random.default_rng(h).integers(0, 256, (3, h, w, 3), dtype=np.uint8))
+    for dt in (torch.float32, torch.float16):
+        want = preprocess_batch(img, True, dt)
+        got = preprocess_batch(img.cuda(), True, dt).cpu()
+        assert got.shape == want.shape and torch.equal(got, want)
+        assert torch.equal(preprocess_batch(img.cuda(), False, dt).cpu(), preprocess_batch(img, False, dt))

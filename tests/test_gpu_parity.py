@@ -209,3 +209,40 @@ def test_full_size_properties(torch_cuda, oracle):
         if not want["sort_oob"]:
             _records_vs_oracle(r1[i], want, f"batch image {i}")
     post.close()
+
+
+def test_reference_shaped_parse_skeletons_surface(torch_cuda, oracle):
+    """utils.parse_skeletons.{heatmap_nms, find_peaks_refactor, predict_refactor} (reference signatures, GPU inside)."""
+    import os
+    from conftest import GOLDEN
+    from posepaf import synth
+    from utils import parse_skeletons as ps
+    net = synth.make_net_output(7, 77, dtype=np.float32)
+    heat, paf = oracle.flip_average(net)
+    hwc = np.ascontiguousarray(heat.transpose(1, 2, 0))
+    got = ps.heatmap_nms(hwc, 4)
+    want, _ = oracle.heatmap_nms(heat, 4, refine=True)
+    assert len(got) == 18
+    assert np.array_equal(np.concatenate(got), want[:, :4])
+    got0 = ps.heatmap_nms(hwc, 4, bool_refine_center=False)
+    want0, _ = oracle.heatmap_nms(heat, 4, refine=False)
+    assert np.array_equal(np.concatenate(got0), want0[:, :4])
+    g = np.load(os.path.join(GOLDEN, "g2_find_peaks.npz"))          # scipy-based reference outputs
+    for i in (0, 3, 4, 5, 7):
+        assert np.array_equal(ps.find_peaks_refactor(0.1, g[f"map{i}"]), g[f"peaks{i}"].reshape(-1, 2)), i
+    from posepaf._lib import PosePafError
+    with pytest.raises(PosePafError):      # 4430 peaks in one channel: refused loudly, not silently truncated
+        ps.find_peaks_refactor(0.1, g["map1"])
+    # predict_refactor: model -> flip-averaged HWC maps == numpy expression of :82-103 on the model's own output
+    from posepaf.fused_model import build_inference_model
+    from posepaf.pipeline import preprocess_batch
+    model = build_inference_model(torch_cuda.device("cuda", 0))
+    img = np.random.default_rng(2).integers(0, 256, (100, 150, 3), dtype=np.uint8)
+    h_, p_ = ps.predict_refactor(img, model, {"rotation_search": [0.0]}, {}, "x.jpg", flip_avg=True)
+    assert h_.shape == (32, 48, 20) and p_.shape == (32, 48, 30) and h_.dtype == np.float32
+    with torch_cuda.no_grad():
+        out = model(preprocess_batch(torch_cuda.from_numpy(img).cuda()[None], True, torch_cuda.float16)).cpu().numpy()
+    hh, pp = oracle.flip_average(out)
+    assert np.allclose(h_, hh.transpose(1, 2, 0), atol=2e-2) and np.allclose(p_, pp.transpose(1, 2, 0), atol=2e-2)
+    with pytest.raises(NotImplementedError):
+        ps.find_connections()

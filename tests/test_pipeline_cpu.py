@@ -1,0 +1,33 @@
+"""CPU: pre-processing formula (A0) against the reference's padRightDownCorner output (golden) and the
+numpy expression of utils/parse_skeletons.py:54-72."""
+import os
+
+import numpy as np
+import torch
+
+from conftest import GOLDEN
+
+
+def test_u8_over_255_float32_equals_float64_division_rounded():
+    x = np.arange(256, dtype=np.uint8)
+    want = np.float32(x / 255)                      # what the reference computes (:60)
+    got = (torch.from_numpy(x).to(torch.float32) / 255.0).numpy()
+    assert np.array_equal(got, want)
+
+
+def test_preprocess_matches_reference_padding_and_flip():
+    from posepaf.pipeline import preprocess_batch
+    g = np.load(os.path.join(GOLDEN, "g4_util.npz"))
+    img, padded, pad = g["img"], g["padded"], g["pad"]          # util.padRightDownCorner(img, 64, 128) from the reference
+    assert padded.shape == (64, 128, 3) and list(pad) == [0, 0, 27, 58]
+    want0 = np.float32(padded / 255)                             # :60
+    want1 = want0[:, ::-1, :]                                    # :69
+    out = preprocess_batch(torch.from_numpy(img[None]), flip=True, dtype=torch.float32).numpy()
+    assert out.shape == (2, 64, 128, 3)
+    assert np.array_equal(out[0], want0) and np.array_equal(out[1], want1)
+    single = preprocess_batch(torch.from_numpy(img[None]), flip=False).numpy()
+    assert np.array_equal(single[0], want0)
+    # already aligned sizes are left alone
+    a = np.random.default_rng(0).integers(0, 256, (2, 64, 64, 3), dtype=np.uint8)
+    o = preprocess_batch(torch.from_numpy(a), flip=True).numpy()
+    assert o.shape == (4, 64, 64, 3) and np.array_equal(o[2], np.float32(a[1] / 255)) and np.array_equal(o[3], o[2][:, ::-1])
