@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""evaluate.py -- the reference's evaluation loop (evaluate.py:235-330) on the MI355X-native path.
+
+    python evaluate.py --run_refactor --run_cpp --synthetic 64 [--batch 16] [--dump_name results.json]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 evaluate.py --synthetic 5000 ...
+
+What is kept from the reference: the flags --run_refactor / --run_cpp (:53-54; this build only implements that
+combination, the README's 65.8-AP / 7.3-fps row), the per-image result format (append_result :182-209) and the
+COCO-style JSON dump (:269-270).  What changes: images are processed in batches, sharded i mod W over the ranks, with one
+RCCL all-gather of the fixed-size records; nothing is copied to the host before the final records.
+
+Offline there are no COCO images, annotations or pretrained weights, so the data source is synthetic: random uint8
+images through the (randomly initialised or checkpoint-loaded) network, with ground-truth-style pose scenes injected
+into the network output; the injected scenes' joints serve as ground truth for the in-repo OKS evaluation
+(posepaf/oks_eval.py; pycocotools is absent).  With --checkpoint_path and --images DIR (npy files of BGR uint8 arrays
+of one common size) the same loop runs on real inputs.
+"""
+import argparse
+import glob
+import json
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from posepaf import coco, dist as pdist, oks_eval, synth  # noqa: E402
+from posepaf._lib import RECORD_BYTES  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser(description="PoseNet evaluation (MI355X-native path)")
+    ap.add_argument("--run_refactor", action="store_true")
+    ap.add_argument("--run_cpp", action="store_true")
+    ap.add_argument("--checkpoint_path", "-p", default=None, help="reference checkpoint (.pth with a 'weights' entry)")
+    ap.add_argument("--synthetic", type=int, default=0, help="number of synthetic 512x512 images")
+    ap.add_argument("--images", default=None, help="directory of .npy BGR uint8 images (all the same size)")
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--dump_name", default="results.json")
+    ap.add_argument("--people", type=int, nargs="*", default=[1, 2, 3, 4, 6, 8, 10, 5])
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    if not (a.run_refactor and a.run_cpp):
+        raise SystemExit("only --run_refactor --run_cpp (the C++-pafprocess semantics) is implemented on this path")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "evaluate.py needs MI355X GPUs"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    torch.backends.cudnn.benchmark = True
+
+    from config.config import GetConfig, TrainingOpt
+    from models.posenet import NetworkEval
+    from posepaf.api import PosePostProcessor
+    from posepaf.fused_model import FusedIMHN
+    from posepaf.model_init import deterministic_init
+    from posepaf.pipeline import PosePipeline
+
+    opt, config = TrainingOpt(), GetConfig(TrainingOpt.config_name)
+    net = NetworkEval(opt, config, bn=True).eval()
+    if a.checkpoint_path:
+        ckpt = torch.load(a.checkpoint_path, map_location="cpu", weights_only=True)
+        net.load_state_dict(ckpt["weights"])       # evaluate.py:308-309 (strict)
+    else:
+        deterministic_init(net, 7)
+    model = FusedIMHN.from_network(net).eval().to(dev).half().to(memory_format=torch.channels_last)
+
+    # ---- data
+    if a.images:
+        files = sorted(glob.glob(os.path.join(a.images, "*.npy")))
+        n_images = len(files)
+        load = lambda i: np.load(files[i])  # noqa: E731
+        image_ids = [os.path.splitext(os.path.basename(f))[0] for f in files]
+        gts, inject_for = {}, None
+    else:
+        n_images = a.synthetic
+        rng = np.random.default_rng(0)
+        image_ids = list(range(n_images))
+        load = lambda i: np.random.default_rng(10_000 + i).integers(0, 256, (512, 512, 3), dtype=np.uint8)  # noqa: E731
+        gts = {}
+        scene_cache = {}
+
+        def inject_for(i):
+            p = a.people[i % len(a.people)]
+            key = (p, i % 64)
+            if key not in scene_cache:
+                scene_cache[key] = synth.make_scene(p, 20_000 + key[1], dtype=np.float16)
+            return scene_cache[key]
+        del rng
+    if n_images == 0:
+        raise SystemExit("nothing to evaluate: pass --synthetic N or --images DIR")
+
+    B = a.batch
+    mine = pdist.shard_indices(n_images, rank, world)
+    S = pdist.padded_shard_size(n_images, world)
+    S_pad = -(-S // B) * B
+    first = load(int(mine[0])) if len(mine) else load(0)
+    H, W = first.shape[:2]
+    hp, wp = -(-H // 64) * 64 // 4, -(-W // 64) * 64 // 4
+    post = PosePostProcessor(max_batch=B, max_h=hp, max_w=wp, max_peaks_per_part=64, device=local)
+    pipe = PosePipeline(model, post)
+    local_recs = torch.zeros(S_pad * RECORD_BYTES, dtype=torch.uint8, device=dev)
+    scale = torch.tensor(1e-3, dtype=torch.float16, device=dev)
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for b0 in range(0, len(mine), B):
+        idx = mine[b0:b0 + B]
+        imgs = np.stack([load(int(i)) for i in idx] + [np.zeros((H, W, 3), np.uint8)] * (B - len(idx)))
+        dev_imgs = torch.from_numpy(imgs).to(dev, non_blocking=True)
+        maps = pipe.forward_maps(dev_imgs)
+        if inject_for is not None:
+            inj = np.stack([inject_for(int(i))[0] for i in idx] + [np.zeros((2, 50, hp, wp), np.float16)] * (B - len(idx)))
+            maps = torch.addcmul(torch.from_numpy(inj).to(dev), maps, scale)
+        rec = post.process_async(maps, H, True)          # min_img_size = img_h (evaluate.py:110)
+        local_recs[b0 * RECORD_BYTES:(b0 + B) * RECORD_BYTES].copy_(rec)
+    torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0
+
+    if world > 1:
+        merged = pdist.gather_records(local_recs[:S * RECORD_BYTES], len(mine))
+    else:
+        from posepaf.api import records_to_numpy
+        merged = records_to_numpy(local_recs[:len(mine) * RECORD_BYTES])
+
+    if rank == 0:
+        results, dts = [], {}
+        for i, rec in enumerate(merged):
+            humans = coco.humans_from_record(rec)
+            res = coco.coco_results(image_ids[i], humans)     # evaluate.py:182-209
+            results.extend(res)
+            dts[image_ids[i]] = [{"keypoints": r["keypoints"], "score": r["score"]} for r in res]
+            if inject_for is not None:
+                gts[image_ids[i]] = oks_eval.gt_from_synth_joints(inject_for(i)[1])
+        with open(a.dump_name, "w") as f:
+            json.dump(results, f)
+        summary = {"images": int(n_images), "world": world, "images_per_sec_rank0": len(mine) / dt_local,
+                   "people_found": len(results), "status_or": int(np.bitwise_or.reduce(merged["status"])) if len(merged) else 0}
+        if gts:
+            summary["synthetic_oks"] = oks_eval.evaluate_keypoints(gts, dts)
+        print(json.dumps(summary))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -128,6 +128,12 @@ def make_net_output(n_people: int, seed: int, h: int = 128, w: int = 128, noise:
     """One image's network output, shape (2, 50, h, w) (or (1,50,h,w) without flip), `dtype`.
 
     Deterministic in (n_people, seed, h, w, noise, dtype)."""
+    return make_scene(n_people, seed, h, w, noise, dtype, flip, p_missing)[0]
+
+
+def make_scene(n_people: int, seed: int, h: int = 128, w: int = 128, noise: float = 0.02,
+               dtype=np.float16, flip: bool = True, p_missing: float = 0.08):
+    """-> (network output as make_net_output, ground-truth joints (P, 18, 3) in image pixels)."""
     rng = np.random.default_rng(seed)
     joints = random_people(n_people, rng, img_h=h * STRIDE, img_w=w * STRIDE, p_missing=p_missing)
     base = render_maps(joints, h, w)
@@ -137,4 +143,4 @@ def make_net_output(n_people: int, seed: int, h: int = 128, w: int = 128, noise:
     out = np.stack(samples).astype(np.float32)
     if noise > 0:
         out = out + rng.normal(0.0, noise, size=out.shape).astype(np.float32)
-    return np.ascontiguousarray(out.astype(dtype))
+    return np.ascontiguousarray(out.astype(dtype)), joints
