@@ -141,15 +141,21 @@ int pp_debug_set_stamps(long long *stamps_dev) {
 
 int pp_nms_batch(pp_ctx *ctx, int batch, const void *net_out_dev, int dtype, int h, int w, int flip, int refine,
                  float *peaks_dev, int *counts_dev, void *stream) {
+    return pp_nms_batch_ex(ctx, batch, net_out_dev, dtype, h, w, flip, 0, 0.1f, refine ? 1 : 0, peaks_dev, counts_dev, stream);
+}
+
+int pp_nms_batch_ex(pp_ctx *ctx, int batch, const void *net_out_dev, int dtype, int h, int w, int flip, int nms_mode,
+                    float threshold, int refine_mode, float *peaks_dev, int *counts_dev, void *stream) {
     int rc = check_shape(ctx, batch, dtype, h, w);
     if (rc != PP_OK) return rc;
-    if (!net_out_dev) return PP_ERR_BAD_ARG;
+    if (!net_out_dev || nms_mode < 0 || nms_mode > 1 || refine_mode < 0 || refine_mode > 3) return PP_ERR_BAD_ARG;
+    const int refine = refine_mode;
     hipStream_t st = static_cast<hipStream_t>(stream);
     float4 *pk = peaks_dev ? reinterpret_cast<float4 *>(peaks_dev) : ctx->d_peaks;
     int *cn = counts_dev ? counts_dev : ctx->d_counts;
     PP_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(unsigned) * (size_t)batch, st));
-    PP_HIP(ctx, pp::launch_heat_peaks(net_out_dev, dtype, batch, flip ? 2 : 1, h, w, flip, refine, 0, 0.1f, ctx->maxp, pk,
-                                      cn, ctx->d_status, st));
+    PP_HIP(ctx, pp::launch_heat_peaks(net_out_dev, dtype, batch, flip ? 2 : 1, h, w, flip, refine, nms_mode, threshold,
+                                      ctx->maxp, pk, cn, ctx->d_status, st));
     ctx->last_stream = st;
     ctx->last_batch = batch;
     ctx->last_peaks = pk;

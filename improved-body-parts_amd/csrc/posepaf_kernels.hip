@@ -392,7 +392,38 @@ __global__ __launch_bounds__(kThreads) void k_heat_peaks(const T *__restrict__ n
         const int i = s_pk[p];
         const int py = i / w, px = i - py * w;
         float ox, oy, score;
-        if (refine) {
+        if (refine == 2) {
+            // util.refine_centroid (utils/util.py:188-213), radius 2: border peaks are returned unrefined with the raw
+            // score; otherwise offset = sum(box * grid) / sum(box) and score = mean(box).  np.mgrid makes x_grid vary
+            // along ROWS, so the reference's "offset_x" is the row centroid; restated as written.  Sums in f64.
+            if (py - 2 < 0 || py + 3 > h || px - 2 < 0 || px + 3 > w) {
+                ox = (float)px;
+                oy = (float)py;
+                score = ldsf(smap, i);
+            } else {
+                double sx = 0.0, sy = 0.0, sv = 0.0;
+                if (lane < 25) {
+                    const int r = lane / 5, c = lane - r * 5;
+                    const double v = (double)ldsf(smap, (py - 2 + r) * w + (px - 2 + c));
+                    sx = v * (double)(r - 2);
+                    sy = v * (double)(c - 2);
+                    sv = v;
+                }
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) {
+                    sx += __shfl_xor(sx, d);
+                    sy += __shfl_xor(sy, d);
+                    sv += __shfl_xor(sv, d);
+                }
+                ox = (float)((double)px + sx / sv);
+                oy = (float)((double)py + sy / sv);
+                score = (float)(sv / 25.0);
+            }
+        } else if (refine == 3) {
+            ox = (float)px;
+            oy = (float)py;
+            score = ldsf(smap, i);
+        } else if (refine == 1) {
             const int x_min = px - 2 < 0 ? 0 : px - 2, y_min = py - 2 < 0 ? 0 : py - 2;  // win_size 2, :135,:143-144
             const int x_max = px + 2 > w - 1 ? w - 1 : px + 2, y_max = py + 2 > h - 1 ? h - 1 : py + 2;
             const int pw = x_max - x_min + 1, ph = y_max - y_min + 1;

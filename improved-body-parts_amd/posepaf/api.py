@@ -82,6 +82,16 @@ class PosePostProcessor:
                                        int(flip), int(refine), None, None, C.c_void_p(stream)), self.ctx)
         return [self.read_peaks(i) for i in range(B)]
 
+    def nms_ex(self, net_out, flip: bool = True, nms_mode: int = 0, threshold: float = 0.1, refine_mode: int = 1):
+        """pp_nms_batch_ex: the original path's 3x3 / >= NMS (nms_mode 1) and refine_centroid (refine_mode 2)."""
+        import torch
+        B, h, w = self._check_input(net_out, flip)
+        stream = torch.cuda.current_stream(net_out.device).cuda_stream
+        _lib.check(self.L.pp_nms_batch_ex(self.ctx, B, C.c_void_p(net_out.data_ptr()), self._dtype_code(net_out), h, w,
+                                          int(flip), int(nms_mode), float(threshold), int(refine_mode), None, None,
+                                          C.c_void_p(stream)), self.ctx)
+        return [self.read_peaks(i) for i in range(B)]
+
     def time_kernels(self, net_out, min_img_size: int = 512, flip: bool = True, iters: int = 20):
         """HIP-event timing of each kernel on torch's current stream: dict name -> ms per launch."""
         import torch

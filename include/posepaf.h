@@ -109,6 +109,16 @@ PP_API int pp_process_batch(pp_ctx *ctx, int batch, const void *net_out_dev, int
 PP_API int pp_nms_batch(pp_ctx *ctx, int batch, const void *net_out_dev, int dtype, int h, int w, int flip, int refine,
                  float *peaks_dev, int *counts_dev, void *stream);
 
+/* Same kernel with the original (non-refactored) path's rules selectable:
+ *   nms_mode    0: plus-shaped window, value >  threshold   (find_peaks_refactor, utils/parse_skeletons.py:115-116)
+ *               1: full 3x3 window,    value >= threshold   (util.keypoint_heatmap_nms, utils/util.py:177-185)
+ *   refine_mode 0: (p + 0.5) * 4 - 0.5, raw score            (heatmap_nms with bool_refine_center=False)
+ *               1: x4 bicubic patch arg-max                   (heatmap_nms, :143-163)
+ *               2: 5x5 weighted centroid, score = box mean    (util.refine_centroid, utils/util.py:188-213)
+ *               3: integer map coordinates, raw score */
+PP_API int pp_nms_batch_ex(pp_ctx *ctx, int batch, const void *net_out_dev, int dtype, int h, int w, int flip, int nms_mode,
+                           float threshold, int refine_mode, float *peaks_dev, int *counts_dev, void *stream);
+
 /* Measurement aid: runs the three kernels of pp_process_batch `iters` times EACH on `stream`, bracketed by HIP
  * events on that stream, and returns the average duration of one launch in milliseconds:
  * ms_out[0] = k_heat_peaks, ms_out[1] = k_limb_connect, ms_out[2] = k_assemble.  Blocking. */

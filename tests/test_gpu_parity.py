@@ -246,3 +246,40 @@ def test_reference_shaped_parse_skeletons_surface(torch_cuda, oracle):
     assert np.allclose(h_, hh.transpose(1, 2, 0), atol=2e-2) and np.allclose(p_, pp.transpose(1, 2, 0), atol=2e-2)
     with pytest.raises(NotImplementedError):
         ps.find_connections()
+
+
+def test_original_path_nms_and_centroid_modes(torch_cuda, oracle):
+    """A10 pieces: 3x3 / >= NMS (util.keypoint_heatmap_nms) and refine_centroid, against the reference's own outputs
+    (tests/golden/g4_util.npz) and the oracle."""
+    import os
+    from conftest import GOLDEN
+    from posepaf.api import PosePostProcessor
+    torch = torch_cuda
+    g = np.load(os.path.join(GOLDEN, "g4_util.npz"))
+    hm, kept = g["hm"], g["kept"]                       # (1,18,24,40) and the reference's masked output
+    post = PosePostProcessor(max_batch=1, max_h=64, max_w=64, max_peaks_per_part=128)
+    net = torch.zeros((1, 1, 50, 24, 40), dtype=torch.float32, device="cuda")
+    net[0, 0, 30:48] = torch.from_numpy(hm[0]).cuda()
+    jl = post.nms_ex(net, flip=False, nms_mode=1, threshold=0.1, refine_mode=3)[0]
+    for ch in range(18):
+        rows = jl[jl[:, 4] == ch]
+        want_yx = np.argwhere(kept[0, ch] != 0)          # row-major, like np.nonzero
+        assert np.array_equal(rows[:, :2].astype(int), want_yx[:, ::-1]), ch
+        assert np.array_equal(rows[:, 2], hm[0, ch][want_yx[:, 0], want_yx[:, 1]])
+    # refine_centroid: single-peak maps built around the golden anchors
+    big = g["big"]
+    for (x, y), want in zip(g["anchors"], g["refined"]):
+        m = np.zeros((1, 1, 50, 30, 30), np.float32)
+        m[0, 0, 30] = big * 1e-3                          # keep the box values' RATIOS; below threshold everywhere ...
+        m[0, 0, 30, y, x] = 1.0                           # ... except the anchor, which becomes the only peak
+        src = m[0, 0, 30].copy()
+        got = post.nms_ex(torch.from_numpy(m).cuda(), flip=False, nms_mode=1, threshold=0.5, refine_mode=2)[0]
+        assert len(got) == 1
+        exp = oracle.refine_centroid(src, int(x), int(y), 2)
+        assert np.allclose(got[0, :3], exp, rtol=1e-5, atol=1e-6), (x, y)
+        # the reference's own refine_centroid on the same array (imported in make_golden.py for `big`; here via the
+        # package's numpy restatement, which test_util_golden pins against the golden values)
+        from utils.util import refine_centroid
+        ref = refine_centroid(src, (int(x), int(y)), 2)
+        assert np.allclose(got[0, :3], np.array(ref, np.float64), rtol=1e-5, atol=1e-6)
+    post.close()

@@ -31,3 +31,16 @@ def test_preprocess_matches_reference_padding_and_flip():
     a = np.random.default_rng(0).integers(0, 256, (2, 64, 64, 3), dtype=np.uint8)
     o = preprocess_batch(torch.from_numpy(a), flip=True).numpy()
     assert o.shape == (4, 64, 64, 3) and np.array_equal(o[2], np.float32(a[1] / 255)) and np.array_equal(o[3], o[2][:, ::-1])
+
+
+def test_util_module_matches_reference_golden():
+    """utils.util (package) against the reference's outputs stored in g4_util.npz."""
+    from utils import util
+    g = np.load(os.path.join(GOLDEN, "g4_util.npz"))
+    padded, pad = util.padRightDownCorner(g["img"], 64, 128)
+    assert np.array_equal(padded, g["padded"]) and list(pad) == list(g["pad"])
+    kept = util.keypoint_heatmap_nms(torch.from_numpy(g["hm"]), kernel=3, thre=0.1).numpy()
+    assert np.array_equal(kept, g["kept"])
+    for (x, y), want in zip(g["anchors"], g["refined"]):
+        got = util.refine_centroid(g["big"], (int(x), int(y)), 2)
+        assert np.allclose(np.array(got, np.float64), want, rtol=1e-6, atol=1e-7)
