@@ -29,6 +29,13 @@ for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# one MIOpen user database per rank: eight processes tuning the same shapes must not serialise on one file lock
+_rank = os.environ.get("LOCAL_RANK", "0")
+os.environ.setdefault("MIOPEN_USER_DB_PATH", f"/tmp/posepaf_miopen_db_rank{_rank}")
+os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", f"/tmp/posepaf_miopen_cache_rank{_rank}")
+os.makedirs(os.environ["MIOPEN_USER_DB_PATH"], exist_ok=True)
+os.makedirs(os.environ["MIOPEN_CUSTOM_CACHE_DIR"], exist_ok=True)
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -86,6 +93,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU path)"
+    backend = os.environ.get("POSEPAF_DIST_BACKEND", "nccl")   # "gloo": rehearsal of the N>1 control flow on one GPU
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # MIOpen exhaustive find (miopenFindConvolutionForwardAlgorithm) per conv shape: +30 % over the default heuristic
@@ -94,7 +103,10 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)   # RCCL
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
     from posepaf._lib import RECORD_BYTES
@@ -113,7 +125,8 @@ def main():
     if not a.postproc_only:
         model = build_inference_model(dev, fused=not a.plain_model)
     pipe = PosePipeline(model, post, dtype=torch.float16, flip=True)
-    gathered = torch.empty(world * B * RECORD_BYTES, dtype=torch.uint8, device=dev) if world > 1 else None
+    gdev = dev if backend == "nccl" else torch.device("cpu")
+    gathered = torch.empty(world * B * RECORD_BYTES, dtype=torch.uint8, device=gdev) if world > 1 else None
 
     scale = torch.tensor(1e-3, dtype=torch.float16, device=dev)
     static_images = images.clone()
@@ -147,8 +160,8 @@ def main():
         else:
             with torch.no_grad():
                 rec = body()
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, rec)
+        if world > 1:   # the path's only exchange: fixed-size per-image records, one collective per batch
+            dist.all_gather_into_tensor(gathered, rec if backend == "nccl" else rec.cpu())
         return rec
 
     def fence():
@@ -166,7 +179,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=gdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     recs = records_to_numpy(rec)
@@ -202,7 +215,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes[dom]},
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:   # reported on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(uniq, a.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
