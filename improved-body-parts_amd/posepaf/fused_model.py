@@ -18,6 +18,10 @@ import torch.nn.functional as F
 from torch import nn
 
 LEAK = 0.01
+# Fused MFMA kernel for the supported 1x1 convolutions (csrc/posepaf_pwconv.hip).  Measured on MI355X (tools/pwconv_probe.py,
+# 64x128x128 batch): 2.1-3.2 TB/s, i.e. 0.83-1.21x of MIOpen's CK kernel + the separate epilogue pass, which both already
+# stream near the HBM rate -- not a win yet at one 4-wave workgroup per CU, so it stays off by default.
+USE_PWCONV = False
 
 
 def _cl(t):
@@ -98,8 +102,26 @@ class FConv(nn.Module):
     def conv_only(self, x):
         return F.conv2d(x, self.weight, None, self.stride, self.padding, self.dilation)
 
+    def _pointwise_ok(self, x):
+        if not (USE_PWCONV and x.is_cuda and x.dtype == torch.float16 and self.weight.shape[2:] == (1, 1)
+                and self.stride == (1, 1) and self.padding == (0, 0)):
+            return False
+        from . import _lib
+        return bool(_lib.load().pp_pwconv_supported(self.weight.shape[1], self.weight.shape[0]))
+
     def forward(self, x, res=None, post=None):
         """act(conv(x) + bias (+ res)) (+ post)"""
+        if self._pointwise_ok(x):   # 1x1: one MFMA GEMM with the epilogue fused (csrc/posepaf_pwconv.hip)
+            from . import _lib
+            x = _cl(x)
+            n, k, h, w = x.shape
+            cout = self.weight.shape[0]
+            y = torch.empty((n, cout, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            res = _cl(res) if res is not None else None
+            post = _cl(post) if post is not None else None
+            _lib.check(_lib.load().pp_pwconv_f16(_ptr(x), _ptr(self.weight), _ptr(self.bias), _ptr(res), _ptr(post), _ptr(y),
+                                                 n * h * w, k, cout, LEAK, int(self.act), _stream(x)))
+            return y
         if _use_hip(x, self.weight.shape[0]):
             return hip_bias_act_(self.conv_only(x), self.bias, res, self.act, post)
         y = F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation)

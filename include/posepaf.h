@@ -136,6 +136,15 @@ PP_API int pp_bias_act_f16(void *y, const void *bias, const void *residual, cons
 PP_API int pp_maxpool2_f16(const void *x, void *y, long n, int h_out, int w_out, int channels, void *stream);
 PP_API int pp_upsample2_f16(const void *x, void *y, long n, int h_in, int w_in, int channels, void *stream);
 
+/* Fused point-wise (1x1) convolution on the matrix cores (v_mfma_f32_32x32x16_f16), fp16 in/out, fp32 accumulate:
+ *   y[m][n] = act(sum_k x[m][k] * w[n][k] + bias[n] (+ residual[m][n])) (+ post[m][n])
+ * x: DEVICE [M][K] (channels-last activation, M = batch*H*W), w: DEVICE [N][K] (a (Cout, Cin, 1, 1) conv weight),
+ * bias fp16[N], residual / post optional [M][N], y [M][N]; all 16-byte aligned.  pp_pwconv_supported(K, N) tells whether
+ * the shape is taken (K in {64,128,192,256}, N % 32 == 0, weights fit LDS); other shapes stay on PyTorch-ROCm. */
+PP_API int pp_pwconv_supported(int K, int N);
+PP_API int pp_pwconv_f16(const void *x, const void *w, const void *bias, const void *residual, const void *post, void *y,
+                         long M, int K, int N, float slope, int has_act, void *stream);
+
 /* A0 pre-processing (utils/parse_skeletons.py:52-73, utils/util.py:44-65) of a batch of equally sized BGR uint8 DEVICE
  * images (batch, h, w, 3): pad bottom/right to a multiple of pad_to with pad_value, divide by 255, and write each image
  * followed (flip != 0) by the W-mirror of the PADDED image.  out: DEVICE (batch*(flip?2:1), Hp, Wp, 3), PP_F16 or PP_F32. */

@@ -81,3 +81,38 @@ def test_preprocess_kernel_matches_host_formula(shape):
         got = preprocess_batch(img.cuda(), True, dt).cpu()
         assert got.shape == want.shape and torch.equal(got, want)
         assert torch.equal(preprocess_batch(img.cuda(), False, dt).cpu(), preprocess_batch(img, False, dt))
+
+
+@pytest.mark.parametrize("K,N", [(64, 64), (128, 256), (256, 128), (192, 96), (128, 128), (128, 32)])
+def test_pwconv_mfma_kernel_matches_torch(K, N):
+    """pp_pwconv_f16 (fused 1x1 conv on v_mfma_f32_32x32x16_f16) vs fp32 math on the same fp16 operands.
+    ASYMMETRIC operands (random) and an M that is not a multiple of the 128-row tile."""
+    import ctypes as C
+    from posepaf import _lib
+    L = _lib.load()
+    assert L.pp_pwconv_supported(K, N) == 1
+    g = torch.Generator(device="cpu").manual_seed(K * 1000 + N)
+    M = 128 * 5 + 37
+    x = (torch.randn(M, K, generator=g) * 0.5).half().cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).half().cuda()
+    b = torch.randn(N, generator=g).half().cuda()
+    r = torch.randn(M, N, generator=g).half().cuda()
+    p = torch.randn(M, N, generator=g).half().cuda()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for res, act, post in [(None, 0, None), (None, 1, None), (r, 1, None), (r, 1, p), (None, 0, p)]:
+        y = torch.full((M, N), float("nan"), dtype=torch.float16, device="cuda")
+        rc = L.pp_pwconv_f16(C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()),
+                             C.c_void_p(res.data_ptr()) if res is not None else None,
+                             C.c_void_p(post.data_ptr()) if post is not None else None, C.c_void_p(y.data_ptr()), M, K, N, 0.01, act, st)
+        assert rc == 0
+        ref = (x.float() @ w.float().t() + b.float()).half().float()       # kernel rounds conv + bias to fp16 once
+        if res is not None:
+            ref = ref + res.float()
+        if act:
+            ref = torch.nn.functional.leaky_relu(ref, 0.01)
+        if post is not None:
+            ref = ref + post.float()
+        err = (y.float() - ref).abs().max().item()
+        assert torch.isfinite(y).all()
+        assert err < 2e-2, (K, N, res is not None, act, post is not None, err)
+    assert L.pp_pwconv_supported(384, 192) == 0 and L.pp_pwconv_supported(256, 384) == 0 and L.pp_pwconv_supported(256, 256) == 0
