@@ -78,6 +78,8 @@ class Oracle:
                                    C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
         L.orc_refine_centroid.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.POINTER(C.c_double)]
+        L.orc_py_find_humans.argtypes = [C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]
         L.orc_f32_to_f16.argtypes = [C.c_float]
         L.orc_f32_to_f16.restype = C.c_uint16
         L.orc_f16_to_f32.argtypes = [C.c_uint16]
@@ -152,6 +154,17 @@ class Oracle:
         out = (C.c_double * 3)()
         self.L.orc_refine_centroid(_fp(m), m.shape[0], m.shape[1], x, y, radius, out)
         return tuple(out)
+
+    def py_find_humans(self, joint_list: np.ndarray, paf_hwc: np.ndarray, img_height: int):
+        """find_connections + find_humans (the pure-Python twins): -> persons (P,20,2) float64, n_connections (30,)"""
+        jl = np.ascontiguousarray(joint_list, np.float32).reshape(-1, 5)
+        pm = np.ascontiguousarray(paf_hwc, np.float32)
+        cap = 512
+        out = np.empty((cap, 20, 2), np.float64)
+        ncn = np.zeros(NUM_LIMB, np.int32)
+        n = self.L.orc_py_find_humans(_fp(jl), len(jl), _fp(pm), pm.shape[0], pm.shape[1], pm.shape[2], int(img_height),
+                                      out.ctypes.data_as(C.POINTER(C.c_double)), cap, _ip(ncn))
+        return out[:n].copy(), ncn
 
     # ---- process_paf (same call shape as the reference's SWIG module)
     def process_paf(self, joint_list: np.ndarray, paf_hwc: np.ndarray, min_img_size: int):

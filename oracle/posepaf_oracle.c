@@ -865,3 +865,246 @@ void orc_refine_centroid(const float *map, int h, int w, int x, int y, int radiu
     out[1] = y + sy / s;
     out[2] = s / (double)((2 * radius + 1) * (2 * radius + 1));
 }
+
+/* ------------------------------------------------------------------ A8: the pure-Python twins
+ * find_connections (utils/parse_skeletons.py:324-410) + find_humans (:413-600) on the refactored path's inputs
+ * (peaks from heatmap_nms, float32 up-sampled limb maps), restated with NumPy-2 scalar semantics (the golden vectors
+ * of tests/golden were produced by importing the reference under NumPy 2.2; under the reference's own NumPy 1.16
+ * `float32 + python float` promoted to float64 instead -- the differences are at the 1e-8 level and cannot be pinned
+ * offline).  Rules that differ from the C++ path are marked  [!=cpp]. */
+
+static float f32_pairwise_sum(const float *a, int n) { /* numpy's add.reduce on a contiguous float32 vector */
+    if (n < 8) {
+        float res = 0.f;
+        for (int i = 0; i < n; i++) res += a[i];
+        return res;
+    }
+    float r[8];
+    for (int k = 0; k < 8; k++) r[k] = a[k];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8)
+        for (int k = 0; k < 8; k++) r[k] += a[i + k];
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res += a[i];
+    return res;
+}
+
+typedef struct {
+    int i, j;
+    double score, limb_len, overall;
+    int gen;
+} pycand_t;
+
+static int pycand_cmp(const void *pa, const void *pb) { /* sorted(key=overall, reverse=True): stable */
+    const pycand_t *a = (const pycand_t *)pa, *b = (const pycand_t *)pb;
+    if (a->overall > b->overall) return -1;
+    if (a->overall < b->overall) return 1;
+    return a->gen < b->gen ? -1 : (a->gen > b->gen ? 1 : 0);
+}
+
+int orc_py_find_humans(const float *peaks, int n_peaks, const float *paf, int H, int W, int C, int img_height,
+                       double *persons_out, int cap, int *n_conn_out) {
+    (void)H;
+    /* all_peaks[k]: rows of part k in input order; joint_candidates = the same rows flattened in part order */
+    int *part_idx[ORC_NUM_PART], part_n[ORC_NUM_PART];
+    for (int k = 0; k < ORC_NUM_PART; k++) {
+        part_idx[k] = (int *)malloc(sizeof(int) * (size_t)(n_peaks > 0 ? n_peaks : 1));
+        part_n[k] = 0;
+    }
+    for (int i = 0; i < n_peaks; i++) {
+        int part = (int)peaks[5 * i + 4];
+        part_idx[part][part_n[part]++] = i;
+    }
+    double *cand = (double *)malloc(sizeof(double) * 4 * (size_t)(n_peaks > 0 ? n_peaks : 1)); /* joint_candidates */
+    {
+        int q = 0;
+        for (int k = 0; k < ORC_NUM_PART; k++)
+            for (int t = 0; t < part_n[k]; t++, q++)
+                for (int e = 0; e < 4; e++) cand[4 * q + e] = (double)peaks[5 * part_idx[k][t] + e];
+    }
+    /* ---- find_connections */
+    typedef struct {
+        double src_id, dst_id, score, i, j, limb_len;
+    } conn6;
+    conn6 *conns[ORC_NUM_LIMB];
+    int nconn[ORC_NUM_LIMB], special[ORC_NUM_LIMB];
+    for (int pair = 0; pair < ORC_NUM_LIMB; pair++) {
+        const int ps = LIMB_PAIRS[pair][0], pd = LIMB_PAIRS[pair][1];
+        const int ns = part_n[ps], nd = part_n[pd];
+        conns[pair] = NULL;
+        nconn[pair] = 0;
+        special[pair] = (ns == 0 && nd == 0); /* :340-342 */
+        if (special[pair]) continue;
+        pycand_t *cs = (pycand_t *)malloc(sizeof(pycand_t) * (size_t)(ns * nd > 0 ? ns * nd : 1));
+        int nc = 0;
+        for (int i = 0; i < ns; i++) {
+            const float *S = peaks + 5 * part_idx[ps][i];
+            for (int j = 0; j < nd; j++) {
+                const float *D = peaks + 5 * part_idx[pd][j];
+                const double dx = (double)D[0] - (double)S[0], dy = (double)D[1] - (double)S[1];
+                const double limb_len = sqrt(dx * dx + dy * dy);         /* :352 */
+                long rn = lrint(limb_len + 1.0);                         /* round(): half to even (default mode) */
+                int mid_num = rn < 20 ? (int)rn : 20;                    /* :353 */
+                if (limb_len == 0.0) continue;                           /* :356 */
+                float resp[20];
+                int cnt = 0;
+                for (int t = 0; t < mid_num; t++) {                      /* np.round(np.linspace(...)) :361-362 [!=cpp] */
+                    double lx, ly;
+                    if (mid_num == 1) {
+                        lx = (double)S[0];
+                        ly = (double)S[1];
+                    } else {
+                        const double stepx = dx / (double)(mid_num - 1), stepy = dy / (double)(mid_num - 1);
+                        lx = (stepx == 0.0) ? ((double)t / (double)(mid_num - 1)) * dx + (double)S[0] : (double)t * stepx + (double)S[0];
+                        ly = (stepy == 0.0) ? ((double)t / (double)(mid_num - 1)) * dy + (double)S[1] : (double)t * stepy + (double)S[1];
+                        if (t == mid_num - 1) {
+                            lx = (double)D[0];
+                            ly = (double)D[1];
+                        }
+                    }
+                    const long ix = lrint(lx), iy = lrint(ly);
+                    resp[t] = paf[pair + (size_t)C * ((size_t)ix + (size_t)W * (size_t)iy)];
+                    if (resp[t] > 0.1f) cnt++;                           /* thre2, :375 */
+                }
+                const float mean32 = f32_pairwise_sum(resp, mid_num) / (float)mid_num;
+                const double prior = 0.5 * (double)img_height / limb_len - 1.0;
+                double connect_score; /* :366  min(prior, 0): python min keeps the np.float64 unless 0 < prior */
+                int score_is_f32;
+                if (0.0 < prior) {
+                    connect_score = (double)mean32; /* float32 + int 0 -> float32 */
+                    score_is_f32 = 1;
+                } else {
+                    connect_score = (double)mean32 + prior; /* float32 + float64 -> float64 */
+                    score_is_f32 = 0;
+                }
+                const int criterion1 = (double)cnt > (double)mid_num * 0.8; /* :375 */
+                const int criterion2 = connect_score > 0.0;
+                if (criterion1 && criterion2) {
+                    double half_cs = score_is_f32 ? (double)(0.5f * (float)connect_score) : 0.5 * connect_score;
+                    pycand_t cd;
+                    cd.i = i;
+                    cd.j = j;
+                    cd.score = connect_score;
+                    cd.limb_len = limb_len;
+                    cd.overall = (half_cs + 0.25 * (double)S[2]) + 0.25 * (double)D[2]; /* :381 */
+                    cd.gen = nc;
+                    cs[nc++] = cd;
+                }
+            }
+        }
+        qsort(cs, (size_t)nc, sizeof(pycand_t), pycand_cmp); /* :391 */
+        const int max_conn = ns < nd ? ns : nd;
+        conns[pair] = (conn6 *)malloc(sizeof(conn6) * (size_t)(max_conn > 0 ? max_conn : 1));
+        for (int k = 0; k < nc; k++) { /* :397-407 */
+            int used = 0;
+            for (int q = 0; q < nconn[pair]; q++)
+                if (conns[pair][q].i == (double)cs[k].i || conns[pair][q].j == (double)cs[k].j) used = 1;
+            if (used) continue;
+            if (nconn[pair] >= max_conn) break;
+            conn6 c6;
+            c6.src_id = (double)peaks[5 * part_idx[ps][cs[k].i] + 3];
+            c6.dst_id = (double)peaks[5 * part_idx[pd][cs[k].j] + 3];
+            c6.score = cs[k].score;
+            c6.i = cs[k].i;
+            c6.j = cs[k].j;
+            c6.limb_len = cs[k].limb_len;
+            conns[pair][nconn[pair]++] = c6;
+            if (nconn[pair] >= max_conn) break;
+        }
+        free(cs);
+    }
+    if (n_conn_out)
+        for (int p = 0; p < ORC_NUM_LIMB; p++) n_conn_out[p] = nconn[p];
+
+    /* ---- find_humans: person rows (20, 2) float64: [0..17] = {peak id, limb score}, [18] = {total, -1}, [19] = {count, len} */
+    int np_ = 0, cap_p = 64;
+    double *P = (double *)malloc(sizeof(double) * 40 * (size_t)cap_p);
+#define PR(p, k, e) P[(size_t)40 * (p) + 2 * (k) + (e)]
+    for (int limb = 0; limb < ORC_NUM_LIMB; limb++) {
+        if (special[limb]) continue;
+        const int st = LIMB_PAIRS[limb][0], dt = LIMB_PAIRS[limb][1];
+        for (int ci = 0; ci < nconn[limb]; ci++) {
+            const conn6 L = conns[limb][ci];
+            int idx[2], nf = 0;
+            for (int p = 0; p < np_; p++)
+                if (PR(p, st, 0) == L.src_id || PR(p, dt, 0) == L.dst_id) {
+                    if (nf >= 2) continue; /* :447-449 third and later matches are ignored [!=cpp] */
+                    idx[nf++] = p;
+                }
+            if (nf == 1) {
+                const int p = idx[0];
+                const double dpk = PR(p, dt, 0), dsc = PR(p, dt, 1), plen = PR(p, 19, 1);
+                if ((int)dpk == -1 && plen * 16.0 > L.limb_len) { /* :458 float compare, no int truncation [!=cpp] */
+                    PR(p, dt, 0) = L.dst_id;
+                    PR(p, dt, 1) = L.score;
+                    PR(p, 19, 0) += 1;
+                    PR(p, 19, 1) = L.limb_len > plen ? L.limb_len : plen;
+                    PR(p, 18, 0) += cand[4 * (int)L.dst_id + 2] + L.score;
+                } else if ((int)dpk != (int)L.dst_id && dsc <= L.score && plen * 16.0 > L.limb_len) {
+                    PR(p, 18, 0) -= cand[4 * (int)dpk + 2] + dsc; /* the OLD peak and score are subtracted [!=cpp] */
+                    PR(p, dt, 0) = L.dst_id;
+                    PR(p, dt, 1) = L.score;
+                    PR(p, 19, 1) = L.limb_len > plen ? L.limb_len : plen;
+                    PR(p, 18, 0) += cand[4 * (int)L.dst_id + 2] + L.score;
+                } else if ((int)dpk == (int)L.dst_id && dsc <= L.score) {
+                    PR(p, 18, 0) -= cand[4 * (int)dpk + 2] + dsc;
+                    PR(p, dt, 0) = L.dst_id;
+                    PR(p, dt, 1) = L.score;
+                    PR(p, 19, 1) = L.limb_len > plen ? L.limb_len : plen;
+                    PR(p, 18, 0) += cand[4 * (int)L.dst_id + 2] + L.score;
+                }
+            } else if (nf == 2) {
+                const int p1 = idx[0], p2 = idx[1];
+                const double plen = PR(p1, 19, 1);
+                int shared = 0;
+                double min1 = 0, min2 = 0;
+                int have1 = 0, have2 = 0;
+                for (int k = 0; k < ORC_NUM_PART; k++) {
+                    const int m1 = PR(p1, k, 0) >= 0, m2 = PR(p2, k, 0) >= 0; /* :502-503 `>= 0` [!=cpp] */
+                    if (m1 && m2) shared = 1;
+                    if (m1 && (!have1 || PR(p1, k, 1) < min1)) { min1 = PR(p1, k, 1); have1 = 1; }
+                    if (m2 && (!have2 || PR(p2, k, 1) < min2)) { min2 = PR(p2, k, 1); have2 = 1; }
+                }
+                if (!shared) {
+                    const double mt = min1 < min2 ? min1 : min2;
+                    if (L.score >= 0.7 * mt && L.limb_len < plen * 16.0) { /* :511-512 AND [!=cpp] */
+                        for (int k = 0; k < ORC_NUM_PART; k++)
+                            for (int e = 0; e < 2; e++)
+                                if (PR(p2, k, e) > PR(p1, k, e)) PR(p1, k, e) = PR(p2, k, e); /* np.maximum :516 [!=cpp] */
+                        PR(p1, 19, 0) += PR(p2, 19, 0);
+                        PR(p1, 19, 1) = L.limb_len > plen ? L.limb_len : plen;
+                        PR(p1, 18, 0) += PR(p2, 18, 0) + L.score;
+                        memmove(&PR(p2, 0, 0), &PR(p2 + 1, 0, 0), sizeof(double) * 40 * (size_t)(np_ - p2 - 1));
+                        np_--;
+                    }
+                }
+            } else { /* nobody claims either joint: new person, :583-596 */
+                if (np_ == cap_p) {
+                    cap_p *= 2;
+                    P = (double *)realloc(P, sizeof(double) * 40 * (size_t)cap_p);
+                }
+                for (int k = 0; k < 20; k++) PR(np_, k, 0) = PR(np_, k, 1) = -1.0;
+                PR(np_, st, 0) = L.src_id;
+                PR(np_, st, 1) = L.score;
+                PR(np_, dt, 0) = L.dst_id;
+                PR(np_, dt, 1) = L.score;
+                PR(np_, 19, 0) = 2;
+                PR(np_, 19, 1) = L.limb_len;
+                PR(np_, 18, 0) = (cand[4 * (int)L.src_id + 2] + cand[4 * (int)L.dst_id + 2]) + L.score;
+                np_++;
+            }
+        }
+    }
+    int n_out = 0;
+    for (int p = 0; p < np_; p++) { /* :599-603 */
+        if (PR(p, 19, 0) < 2 || PR(p, 18, 0) / PR(p, 19, 0) < 0.45) continue;
+        if (n_out < cap) memcpy(persons_out + (size_t)40 * n_out, &PR(p, 0, 0), sizeof(double) * 40);
+        n_out++;
+    }
+#undef PR
+    free(P);
+    free(cand);
+    for (int k = 0; k < ORC_NUM_PART; k++) free(part_idx[k]);
+    for (int p = 0; p < ORC_NUM_LIMB; p++) free(conns[p]);
+    return n_out;
+}

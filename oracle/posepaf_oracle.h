@@ -103,6 +103,12 @@ void orc_get_candidate(const orc_ctx *c, int limb, int i, int *idx1, int *idx2, 
 int orc_pipeline(orc_ctx *c, const void *net_out, int is_f16, int h, int w, int flip,
                  int min_img_size, float *peaks_out, int max_peaks, int *n_peaks_out);
 
+/* ---- A8: the pure-Python twins find_connections + find_humans (utils/parse_skeletons.py:324-600), float64, on the
+ * refactored path's inputs.  peaks: joint_list rows [x,y,score,id,part]; paf: (H,W,C) float32.
+ * persons_out: rows of 40 doubles = (20, 2) as in `person_to_joint_assoc`; returns the number of persons. */
+int orc_py_find_humans(const float *peaks, int n_peaks, const float *paf, int H, int W, int C, int img_height,
+                       double *persons_out, int cap, int *n_conn_out);
+
 /* ---- A10: util.refine_centroid, utils/util.py:188-213 (float64 arithmetic like numpy on f32->f64?) ---- */
 void orc_refine_centroid(const float *map, int h, int w, int x, int y, int radius, double out_xys[3]);
 

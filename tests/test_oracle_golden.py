@@ -119,3 +119,19 @@ def test_util_golden(oracle):
     for (x, y), want in zip(g["anchors"], g["refined"]):
         got = oracle.refine_centroid(g["big"], int(x), int(y), 2)
         assert np.allclose(got, want, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("key", scene_keys())
+def test_python_twins_against_reference_outputs(oracle, key):
+    """A8: find_connections + find_humans restated (oracle) vs the reference's own Python run on the same inputs
+    (golden G3: py_persons / py_n_connections, made by importing /root/reference/utils/parse_skeletons.py)."""
+    net, g = load_scene(key)
+    _, paf = oracle.flip_average(net)
+    up = oracle.upsample4_hwc(paf)
+    persons, ncn = oracle.py_find_humans(g["joint_list"], up, 512)
+    assert np.array_equal(ncn, g["py_n_connections"])
+    want = g["py_persons"]
+    assert persons.shape == want.shape
+    assert np.array_equal(persons[:, :, 0], want[:, :, 0])                       # ids, counts, totals' slot layout
+    assert np.allclose(persons[:, :, 1], want[:, :, 1], rtol=0, atol=1e-9)       # limb scores / lengths
+    assert np.allclose(persons[:, 18, 0], want[:, 18, 0], rtol=0, atol=1e-9)
