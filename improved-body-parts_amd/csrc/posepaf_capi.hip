@@ -23,6 +23,7 @@ struct pp_ctx {
     float4 *d_conns = nullptr;    // [max_batch][30][maxp] (cid1 bits, cid2 bits, score, length)
     int *d_conn_counts = nullptr; // [max_batch][30]
     unsigned *d_status = nullptr; // [max_batch]
+    void *d_conns_py = nullptr;   // [max_batch][30][maxp] double4 (src, dst, score, length): Python-twin path
     pp_record *d_records = nullptr;  // [max_batch] (used when the caller passes NULL, and by the drop-in path)
     float *d_paf = nullptr;       // drop-in path: the caller's up-sampled (H,W,C) map
     size_t d_paf_bytes = 0;
@@ -57,6 +58,7 @@ void free_ctx(pp_ctx *c) {
     (void)hipFree(c->d_conns);
     (void)hipFree(c->d_conn_counts);
     (void)hipFree(c->d_status);
+    (void)hipFree(c->d_conns_py);
     (void)hipFree(c->d_records);
     (void)hipFree(c->d_paf);
     delete c;
@@ -114,6 +116,7 @@ int pp_create(pp_ctx **out, int device, int max_batch, int max_h, int max_w, int
     if (e == hipSuccess) e = hipMalloc(&c->d_counts, B * PP_NUM_PART * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&c->d_conns, B * PP_NUM_LIMB * c->maxp * sizeof(float4));
     if (e == hipSuccess) e = hipMalloc(&c->d_conn_counts, B * PP_NUM_LIMB * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&c->d_conns_py, B * PP_NUM_LIMB * c->maxp * 32);
     if (e == hipSuccess) e = hipMalloc(&c->d_status, B * sizeof(unsigned));
     if (e == hipSuccess) e = hipMalloc(&c->d_records, B * sizeof(pp_record));
     if (e == hipSuccess) e = hipMemset(c->d_counts, 0, B * PP_NUM_PART * sizeof(int));
@@ -179,6 +182,33 @@ int pp_process_batch(pp_ctx *ctx, int batch, const void *net_out_dev, int dtype,
                                         ctx->d_status, st));
     PP_HIP(ctx, pp::launch_assemble(batch, ctx->maxp, 0, ctx->d_peaks, ctx->d_counts, ctx->d_conns, ctx->d_conn_counts,
                                     ctx->d_status, rec, st));
+    ctx->last_stream = st;
+    ctx->last_batch = batch;
+    ctx->last_peaks = ctx->d_peaks;
+    ctx->last_counts = ctx->d_counts;
+    return PP_OK;
+}
+
+int pp_process_batch_py(pp_ctx *ctx, int batch, const void *net_out_dev, int dtype, int h, int w, int flip, int img_height,
+                        const int *img_height_dev, pp_record *records_dev, void *stream) {
+    int rc = check_shape(ctx, batch, dtype, h, w);
+    if (rc != PP_OK) return rc;
+    if (!net_out_dev) return PP_ERR_BAD_ARG;
+    const int elem = dtype == PP_F16 ? 2 : 4;
+    if (pp::lds_bytes_limb_py(elem, h, w, ctx->maxp, ctx->cap) > pp::kMaxDynLds ||
+        pp::lds_bytes_assemble_py(ctx->maxp) > pp::kMaxDynLds)
+        return PP_ERR_TOO_LARGE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    pp_record *rec = records_dev ? records_dev : ctx->d_records;
+    const int ns = flip ? 2 : 1;
+    PP_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(unsigned) * (size_t)batch, st));
+    PP_HIP(ctx, pp::launch_heat_peaks(net_out_dev, dtype, batch, ns, h, w, flip, 1, 0, 0.1f, ctx->maxp, ctx->d_peaks,
+                                      ctx->d_counts, ctx->d_status, st));
+    PP_HIP(ctx, pp::launch_limb_connect_py(net_out_dev, dtype, batch, ns, h, w, flip, ctx->maxp, ctx->cap, img_height,
+                                           img_height_dev, ctx->d_peaks, ctx->d_counts, ctx->d_conns_py, ctx->d_conn_counts,
+                                           ctx->d_status, st));
+    PP_HIP(ctx, pp::launch_assemble_py(batch, ctx->maxp, ctx->d_peaks, ctx->d_counts, ctx->d_conns_py, ctx->d_conn_counts,
+                                       ctx->d_status, rec, st));
     ctx->last_stream = st;
     ctx->last_batch = batch;
     ctx->last_peaks = ctx->d_peaks;

@@ -32,5 +32,13 @@ hipError_t launch_assemble(int batch, int maxp, int explicit_ids, const float4 *
                            const float4 *conns, const int *conn_counts, unsigned *status, pp_record *records,
                            hipStream_t stream);
 
+size_t lds_bytes_limb_py(int elem, int h, int w, int maxp, int cap);
+size_t lds_bytes_assemble_py(int maxp);
+hipError_t launch_limb_connect_py(const void *net, int dtype, int batch, int n_samples, int h, int w, int flip, int maxp,
+                                  int cap, int img_height, const int *img_height_dev, const float4 *peaks, const int *counts,
+                                  void *conns, int *conn_counts, unsigned *status, hipStream_t stream);
+hipError_t launch_assemble_py(int batch, int maxp, const float4 *peaks, const int *counts, const void *conns,
+                              const int *conn_counts, unsigned *status, pp_record *records, hipStream_t stream);
+
 }  // namespace pp
 #endif

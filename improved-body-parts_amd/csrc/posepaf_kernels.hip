@@ -1288,6 +1288,512 @@ __global__ __launch_bounds__(64) void k_assemble(int maxp, int explicit_ids, con
     }
 }
 
+// ================================================================================================ A8: Python twins
+// find_connections (utils/parse_skeletons.py:324-410) and find_humans (:413-600): the rules evaluate.py follows WITHOUT
+// --run_cpp.  Same inputs as the C++ path (peaks of K_A, the x4 bicubic limb maps evaluated on the fly), different
+// arithmetic: float64 throughout, np.round(np.linspace) sample positions (round-half-even), NumPy's float32 pairwise
+// mean, a STABLE descending sort, `>= 0` membership, AND merge condition, np.maximum merge, old-value subtraction.
+// Restated with NumPy-2 scalar promotion (see oracle/posepaf_oracle.c, orc_py_find_humans).
+
+struct LimbLdsPy {
+    float *ax, *ay, *as, *bx, *by, *bs;  // [maxp] peak x, y (floats, not truncated), score
+    int *minA, *minB, *usedA, *usedB;    // [maxp]
+    double *key, *c_score, *c_len;       // [cap] overall, connect_score, limb_len
+    int *rank, *order, *state;           // [cap]
+    unsigned *c_idx;                     // [cap]
+};
+__host__ __device__ inline size_t limb_lds_bytes_py(int maxp, int cap) { return 40 * (size_t)maxp + 8 + 40 * (size_t)cap; }
+
+__device__ inline LimbLdsPy carve_limb_lds_py(unsigned char *p, int maxp, int cap) {
+    LimbLdsPy L;
+    float *f = reinterpret_cast<float *>(p);
+    L.ax = f; f += maxp;
+    L.ay = f; f += maxp;
+    L.as = f; f += maxp;
+    L.bx = f; f += maxp;
+    L.by = f; f += maxp;
+    L.bs = f; f += maxp;
+    int *q = reinterpret_cast<int *>(f);
+    L.minA = q; q += maxp;
+    L.minB = q; q += maxp;
+    L.usedA = q; q += maxp;
+    L.usedB = q; q += maxp;
+    uintptr_t u = (reinterpret_cast<uintptr_t>(q) + 7) & ~(uintptr_t)7;
+    double *d = reinterpret_cast<double *>(u);
+    L.key = d; d += cap;
+    L.c_score = d; d += cap;
+    L.c_len = d; d += cap;
+    q = reinterpret_cast<int *>(d);
+    L.rank = q; q += cap;
+    L.order = q; q += cap;
+    L.state = q; q += cap;
+    L.c_idx = reinterpret_cast<unsigned *>(q);
+    return L;
+}
+
+// one (src, dst) pair, utils/parse_skeletons.py:344-388
+template <typename Sampler>
+__device__ bool score_pair_py(const Sampler &smp, float axf, float ayf, float asf, float bxf, float byf, float bsf,
+                              int img_height, double *score_out, double *overall_out, double *len_out) {
+    const double ax = (double)axf, ay = (double)ayf, bx = (double)bxf, by = (double)byf;
+    const double dx = bx - ax, dy = by - ay;
+    const double limb_len = sqrt(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));  // :352
+    if (limb_len == 0.0) return false;                                                // :356
+    const long long rn = __double2ll_rn(limb_len + 1.0);                              // round(): half to even
+    const int mid_num = rn < 20 ? (int)rn : 20;                                       // :353
+    const double div = (double)(mid_num - 1);
+    const double stepx = mid_num > 1 ? dx / div : 0.0, stepy = mid_num > 1 ? dy / div : 0.0;
+    float resp[20];
+    int cnt = 0;
+#pragma unroll
+    for (int t = 0; t < 20; t++) {
+        float v = 0.f;
+        if (t < mid_num) {
+            // np.linspace: arange(num) * step + start, last element overwritten with stop (:361-362); step == 0 -> start
+            double lx = __dadd_rn(__dmul_rn((double)t, stepx), ax), ly = __dadd_rn(__dmul_rn((double)t, stepy), ay);
+            if (mid_num > 1 && t == mid_num - 1) {
+                lx = bx;
+                ly = by;
+            }
+            v = smp.at((int)__double2ll_rn(lx), (int)__double2ll_rn(ly));  // np.round: half to even
+            if (v > 0.1f) cnt++;                                            // thre2 (:375)
+        }
+        resp[t] = v;
+    }
+    // limb_response.mean(): NumPy's float32 pairwise sum (8 running sums once n >= 8), then / n in float32
+    float sum;
+    if (mid_num < 8) {
+        sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 7; t++)
+            if (t < mid_num) sum = __fadd_rn(sum, resp[t]);
+    } else {
+        float r[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) r[k] = resp[k];
+        const int full = mid_num - (mid_num & 7);
+#pragma unroll
+        for (int t = 8; t < 16; t++)
+            if (t < full) r[t & 7] = __fadd_rn(r[t & 7], resp[t]);
+        sum = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
+                        __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
+#pragma unroll
+        for (int t = 8; t < 20; t++)
+            if (t >= full && t < mid_num) sum = __fadd_rn(sum, resp[t]);
+    }
+    const float mean32 = sum / (float)mid_num;
+    const double prior = 0.5 * (double)img_height / limb_len - 1.0;  // :366
+    double connect_score, half_cs;
+    if (0.0 < prior) {  // python min(prior, 0) -> int 0: float32 + 0 stays float32
+        connect_score = (double)mean32;
+        half_cs = (double)__fmul_rn(0.5f, mean32);
+    } else {            // float32 + float64 -> float64
+        connect_score = __dadd_rn((double)mean32, prior);
+        half_cs = __dmul_rn(0.5, connect_score);
+    }
+    if (!((double)cnt > __dmul_rn((double)mid_num, 0.8) && connect_score > 0.0)) return false;  // :375-378
+    *overall_out = __dadd_rn(__dadd_rn(half_cs, __dmul_rn(0.25, (double)asf)), __dmul_rn(0.25, (double)bsf));  // :381
+    *score_out = connect_score;
+    *len_out = limb_len;
+    return true;
+}
+
+// LDS (dynamic): [map h*w T][cubic 16 f32][LimbLdsPy]
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_limb_connect_py(const T *__restrict__ net, int n_samples, int h, int w,
+                                                              int flip, int maxp, int cap, int img_height,
+                                                              const int *__restrict__ img_height_dev,
+                                                              const float4 *__restrict__ peaks,
+                                                              const int *__restrict__ counts, double4 *__restrict__ conns,
+                                                              int *__restrict__ conn_counts,
+                                                              unsigned *__restrict__ status) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    __shared__ int s_wcnt[2][kWaves];
+    const int limb = blockIdx.x, img = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pa = d_limb_pairs[limb][0], pb = d_limb_pairs[limb][1];
+    int nA = counts[img * PP_NUM_PART + pa], nB = counts[img * PP_NUM_PART + pb];
+    nA = nA < maxp ? nA : maxp;
+    nB = nB < maxp ? nB : maxp;
+    int *cc = conn_counts + img * PP_NUM_LIMB + limb;
+    if (nA == 0 || nB == 0) {
+        if (threadIdx.x == 0) *cc = 0;
+        return;
+    }
+    const int npix = h * w;
+    size_t off = 0;
+    T *smap = reinterpret_cast<T *>(lds_raw);
+    off += (sizeof(T) * (size_t)npix + 15) & ~(size_t)15;
+    float *s_cub = reinterpret_cast<float *>(lds_raw + off);
+    off += 64;
+    LimbLdsPy L = carve_limb_lds_py(lds_raw + off, maxp, cap);
+    if (threadIdx.x < 16) s_cub[threadIdx.x] = d_cubic4[threadIdx.x >> 2][threadIdx.x & 3];
+    const float4 *pka = peaks + ((size_t)img * PP_NUM_PART + pa) * maxp;
+    const float4 *pkb = peaks + ((size_t)img * PP_NUM_PART + pb) * maxp;
+    for (int i = threadIdx.x; i < nA; i += kThreads) {
+        const float4 p = pka[i];
+        L.ax[i] = p.x;
+        L.ay[i] = p.y;
+        L.as[i] = p.z;
+    }
+    for (int i = threadIdx.x; i < nB; i += kThreads) {
+        const float4 p = pkb[i];
+        L.bx[i] = p.x;
+        L.by[i] = p.y;
+        L.bs[i] = p.z;
+    }
+    for (int i = threadIdx.x; i < maxp; i += kThreads) {
+        L.usedA[i] = 0;
+        L.usedB[i] = 0;
+    }
+    const size_t plane = (size_t)npix;
+    const T *o0 = net + ((size_t)img * n_samples * PP_NUM_CH + limb) * plane;
+    const T *o1 = net + (((size_t)img * n_samples + 1) * PP_NUM_CH + d_flip_paf_ord[limb]) * plane;
+    load_channel(smap, o0, o1, h, w, flip != 0);
+    __syncthreads();
+    LdsBicubicSampler<T> smp{smap, s_cub, h, w};
+    const int ih = img_height_dev ? img_height_dev[img] : img_height;
+
+    // ---- scoring + ordered compaction (generation order: src outer, dst inner)
+    const int npairs = nA * nB;
+    int ncand = 0, buf = 0;
+    for (int base = 0; base < npairs; base += kThreads, buf ^= 1) {
+        const int p = base + threadIdx.x;
+        bool ok = false;
+        double sc = 0, ov = 0, ln = 0;
+        int ia = 0, ib = 0;
+        if (p < npairs) {
+            ia = p / nB;
+            ib = p - ia * nB;
+            ok = score_pair_py(smp, L.ax[ia], L.ay[ia], L.as[ia], L.bx[ib], L.by[ib], L.bs[ib], ih, &sc, &ov, &ln);
+        }
+        const unsigned long long m = __ballot(ok);
+        if (lane == 0) s_wcnt[buf][wave] = __popcll(m);
+        __syncthreads();
+        int before = 0, all = 0;
+#pragma unroll
+        for (int k = 0; k < kWaves; k++) {
+            const int c = s_wcnt[buf][k];
+            if (k < wave) before += c;
+            all += c;
+        }
+        if (ok) {
+            const int pos = ncand + before + __popcll(m & lanemask_lt());
+            if (pos < cap) {
+                L.key[pos] = ov;
+                L.c_score[pos] = sc;
+                L.c_len[pos] = ln;
+                L.c_idx[pos] = (unsigned)ia | ((unsigned)ib << 16);
+            }
+        }
+        ncand += all;
+    }
+    unsigned st = 0;
+    if (ncand > cap) {
+        st |= PP_ST_CAND_OVERFLOW;
+        ncand = cap;
+    }
+    const int n = ncand;
+    __syncthreads();
+    // ---- sorted(reverse=True) is stable: equal keys keep generation order (:391)
+    for (int t = threadIdx.x; t < n; t += kThreads) {
+        const double kt = L.key[t];
+        int r = 0;
+        for (int j = 0; j < n; j++) {
+            const double kj = L.key[j];
+            r += (kj > kt) || (kj == kt && j < t);
+        }
+        L.rank[t] = r;
+        L.state[t] = 0;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < n; t += kThreads) L.order[L.rank[t]] = t;
+    __syncthreads();
+    // ---- greedy pick (:393-407) as repeated acceptance of locally dominant candidates (see connect_limb)
+    while (true) {
+        for (int i = threadIdx.x; i < maxp; i += kThreads) {
+            L.minA[i] = 0x7fffffff;
+            L.minB[i] = 0x7fffffff;
+        }
+        __syncthreads();
+        bool live = false;
+        for (int t = threadIdx.x; t < n; t += kThreads) {
+            if (L.state[t] == 0) {
+                const unsigned idx = L.c_idx[t];
+                const int ia = (int)(idx & 0xffffu), ib = (int)(idx >> 16);
+                if (L.usedA[ia] || L.usedB[ib]) {
+                    L.state[t] = 2;
+                } else {
+                    atomicMin(&L.minA[ia], L.rank[t]);
+                    atomicMin(&L.minB[ib], L.rank[t]);
+                    live = true;
+                }
+            }
+        }
+        if (!__syncthreads_or(live)) break;
+        for (int t = threadIdx.x; t < n; t += kThreads) {
+            if (L.state[t] == 0) {
+                const unsigned idx = L.c_idx[t];
+                const int ia = (int)(idx & 0xffffu), ib = (int)(idx >> 16);
+                const int r = L.rank[t];
+                if (L.minA[ia] == r && L.minB[ib] == r) {
+                    L.state[t] = 1;
+                    L.usedA[ia] = 1;
+                    L.usedB[ib] = 1;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    double4 *conn_out = conns + ((size_t)img * PP_NUM_LIMB + limb) * maxp;
+    int ncn = 0;
+    for (int base = 0; base < n; base += kThreads, buf ^= 1) {
+        const int r = base + threadIdx.x;
+        bool acc = false;
+        int t = 0;
+        if (r < n) {
+            t = L.order[r];
+            acc = L.state[t] == 1;
+        }
+        const unsigned long long m = __ballot(acc);
+        if (lane == 0) s_wcnt[buf][wave] = __popcll(m);
+        __syncthreads();
+        int before = 0, all = 0;
+#pragma unroll
+        for (int k = 0; k < kWaves; k++) {
+            const int c = s_wcnt[buf][k];
+            if (k < wave) before += c;
+            all += c;
+        }
+        if (acc) {
+            const unsigned idx = L.c_idx[t];
+            conn_out[ncn + before + __popcll(m & lanemask_lt())] =
+                make_double4((double)(idx & 0xffffu), (double)(idx >> 16), L.c_score[t], L.c_len[t]);
+        }
+        ncn += all;
+    }
+    if (threadIdx.x == 0) {
+        *cc = ncn;
+        if (st) atomicOr(status + img, st);
+    }
+}
+
+// find_humans, one wave per image, float64 person table in LDS: [s][k] = {id, score}; k = 18: {total, -1}; 19: {count, len}
+constexpr int kMaxSkelPy = 128;
+__host__ __device__ inline size_t assemble_py_lds_bytes(int maxp) {
+    return (size_t)kMaxSkelPy * kSkelStride * 16 + (size_t)PP_NUM_PART * maxp * 16 + (size_t)PP_NUM_LIMB * maxp * 32;
+}
+
+__global__ __launch_bounds__(64) void k_assemble_py(int maxp, const float4 *__restrict__ peaks, const int *__restrict__ counts,
+                                                    const double4 *__restrict__ conns, const int *__restrict__ conn_counts,
+                                                    unsigned *__restrict__ status, pp_record *__restrict__ records) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int img = blockIdx.x, lane = threadIdx.x;
+    const int ntab = PP_NUM_PART * maxp;
+    double *pid = reinterpret_cast<double *>(lds_raw);                 // [kMaxSkelPy][21]
+    double *psc = pid + kMaxSkelPy * kSkelStride;
+    double4 *s_conn = reinterpret_cast<double4 *>(psc + kMaxSkelPy * kSkelStride);  // {src_id, dst_id, score, len}
+    int *line_x = reinterpret_cast<int *>(s_conn + PP_NUM_LIMB * maxp);
+    int *line_y = line_x + ntab;
+    float *line_s = reinterpret_cast<float *>(line_y + ntab);
+    __shared__ int s_off[PP_NUM_PART + 1];
+    __shared__ int s_cnt[PP_NUM_PART];
+    __shared__ int s_coff[PP_NUM_LIMB + 1];
+    __shared__ int s_merge;
+
+    const int *cnt_g = counts + img * PP_NUM_PART;
+    const float4 *pk_g = peaks + (size_t)img * PP_NUM_PART * maxp;
+    if (lane == 0) {
+        int run = 0;
+        for (int k = 0; k < PP_NUM_PART; k++) {
+            int c = cnt_g[k];
+            c = c < maxp ? c : maxp;
+            s_cnt[k] = c;
+            s_off[k] = run;
+            run += c;
+        }
+        s_off[PP_NUM_PART] = run;
+        run = 0;
+        for (int l = 0; l < PP_NUM_LIMB; l++) {
+            s_coff[l] = run;
+            int c = conn_counts[img * PP_NUM_LIMB + l];
+            run += c < maxp ? c : maxp;
+        }
+        s_coff[PP_NUM_LIMB] = run;
+    }
+    __syncthreads();
+    const int n_peaks = s_off[PP_NUM_PART];
+    for (int part = 0; part < PP_NUM_PART; part++) {  // joint_candidates: rows flattened in part order (:423)
+        const int c = s_cnt[part], o = s_off[part];
+        for (int r = lane; r < c; r += 64) {
+            const float4 p = pk_g[(size_t)part * maxp + r];
+            line_x[o + r] = (int)p.x;
+            line_y[o + r] = (int)p.y;
+            line_s[o + r] = p.z;
+        }
+    }
+    for (int limb = 0; limb < PP_NUM_LIMB; limb++) {
+        const int c = s_coff[limb + 1] - s_coff[limb], o = s_coff[limb];
+        const int part1 = d_limb_pairs[limb][0], part2 = d_limb_pairs[limb][1];
+        const double4 *cn_g = conns + ((size_t)img * PP_NUM_LIMB + limb) * maxp;
+        for (int ci = lane; ci < c; ci += 64) {
+            double4 cn = cn_g[ci];
+            cn.x = (double)(s_off[part1] + (int)cn.x);  // peak id == position in the part-ordered joint list
+            cn.y = (double)(s_off[part2] + (int)cn.y);
+            s_conn[o + ci] = cn;
+        }
+    }
+    __syncthreads();
+
+    int np = 0;  // uniform
+    unsigned st = 0;
+    for (int limb = 0; limb < PP_NUM_LIMB; limb++) {
+        const int part1 = d_limb_pairs[limb][0], part2 = d_limb_pairs[limb][1];
+        for (int ci = s_coff[limb]; ci < s_coff[limb + 1]; ci++) {
+            const double4 cn = s_conn[ci];
+            const double src_id = cn.x, dst_id = cn.y, score = cn.z, limb_len = cn.w;
+            int num_found = 0, idx1 = 0, idx2 = 0;
+            for (int base = 0; base < np; base += 64) {  // :440-450; matches beyond the second are ignored
+                const int s = base + lane;
+                bool hit = false;
+                if (s < np) hit = (pid[s * kSkelStride + part1] == src_id) || (pid[s * kSkelStride + part2] == dst_id);
+                unsigned long long m = __ballot(hit);
+                if (m) {
+                    if (num_found == 0) {
+                        idx1 = base + __ffsll((long long)m) - 1;
+                        const unsigned long long m2 = m & (m - 1);
+                        if (m2) idx2 = base + __ffsll((long long)m2) - 1;
+                    } else if (num_found == 1) {
+                        idx2 = base + __ffsll((long long)m) - 1;
+                    }
+                    num_found += __popcll(m);
+                }
+            }
+            if (num_found > 2) num_found = 2;
+            const double ps_src = (double)line_s[(int)src_id], ps_dst = (double)line_s[(int)dst_id];
+            if (num_found == 1) {  // :452-487
+                if (lane == 0) {
+                    double *i1 = pid + idx1 * kSkelStride, *f1 = psc + idx1 * kSkelStride;
+                    const double dpk = i1[part2], dsc = f1[part2], plen = f1[19];
+                    const bool len_ok = __dmul_rn(plen, 16.0) > limb_len;
+                    if ((int)dpk == -1 && len_ok) {
+                        i1[part2] = dst_id;
+                        f1[part2] = score;
+                        i1[19] += 1.0;
+                        f1[19] = limb_len > plen ? limb_len : plen;
+                        i1[18] = __dadd_rn(i1[18], __dadd_rn(ps_dst, score));
+                    } else if (((int)dpk != (int)dst_id && dsc <= score && len_ok) || ((int)dpk == (int)dst_id && dsc <= score)) {
+                        // the OLD peak's score and the OLD limb score are subtracted first (:477-480)
+                        const int old = (int)dpk;
+                        const double old_ps = (old >= 0 && old < n_peaks) ? (double)line_s[old] : 0.0;
+                        i1[18] = __dadd_rn(i1[18], -__dadd_rn(old_ps, dsc));
+                        i1[part2] = dst_id;
+                        f1[part2] = score;
+                        f1[19] = limb_len > plen ? limb_len : plen;
+                        i1[18] = __dadd_rn(i1[18], __dadd_rn(ps_dst, score));
+                    }
+                }
+                __syncthreads();
+            } else if (num_found == 2) {  // :489-560
+                if (lane == 0) {
+                    double *i1 = pid + idx1 * kSkelStride, *f1 = psc + idx1 * kSkelStride;
+                    double *i2 = pid + idx2 * kSkelStride, *f2 = psc + idx2 * kSkelStride;
+                    const double plen = f1[19];
+                    bool shared = false, have1 = false, have2 = false;
+                    double min1 = 0, min2 = 0;
+                    for (int k = 0; k < PP_NUM_PART; k++) {
+                        const bool m1 = i1[k] >= 0, m2 = i2[k] >= 0;  // :502-503
+                        if (m1 && m2) shared = true;
+                        if (m1 && (!have1 || f1[k] < min1)) { min1 = f1[k]; have1 = true; }
+                        if (m2 && (!have2 || f2[k] < min2)) { min2 = f2[k]; have2 = true; }
+                    }
+                    int merge = 0;
+                    if (!shared) {
+                        const double mt = min1 < min2 ? min1 : min2;
+                        if (score >= __dmul_rn(0.7, mt) && limb_len < __dmul_rn(plen, 16.0)) {  // :511-512 AND
+                            for (int k = 0; k < PP_NUM_PART; k++) {  // np.maximum on (18, 2), :516
+                                if (i2[k] > i1[k]) i1[k] = i2[k];
+                                if (f2[k] > f1[k]) f1[k] = f2[k];
+                            }
+                            i1[19] += i2[19];
+                            f1[19] = limb_len > plen ? limb_len : plen;
+                            i1[18] = __dadd_rn(i1[18], __dadd_rn(i2[18], score));
+                            merge = 1;
+                        }
+                    }
+                    s_merge = merge;
+                }
+                __syncthreads();
+                if (s_merge) {  // np.delete(person2)
+                    for (int s = idx2; s < np - 1; s++) {
+                        if (lane < 20) {
+                            pid[s * kSkelStride + lane] = pid[(s + 1) * kSkelStride + lane];
+                            psc[s * kSkelStride + lane] = psc[(s + 1) * kSkelStride + lane];
+                        }
+                    }
+                    np--;
+                }
+                __syncthreads();
+            } else {  // new person, :583-596
+                if (np < kMaxSkelPy) {
+                    if (lane < 20) {
+                        double idv = -1.0, scv = -1.0;
+                        if (lane == part1) { idv = src_id; scv = score; }
+                        if (lane == part2) { idv = dst_id; scv = score; }
+                        if (lane == 19) { idv = 2.0; scv = limb_len; }
+                        if (lane == 18) idv = __dadd_rn(__dadd_rn(ps_src, ps_dst), score);
+                        pid[np * kSkelStride + lane] = idv;
+                        psc[np * kSkelStride + lane] = scv;
+                    }
+                    np++;
+                } else {
+                    st |= PP_ST_SKEL_OVERFLOW;
+                }
+                __syncthreads();
+            }
+        }
+    }
+    // ---- prune (:599-603) and records (evaluate.py:132-156: x, y, score from joint_candidates; score = total / count)
+    pp_record *rec = records + img;
+    int n_out = 0;
+    for (int base = 0; base < np; base += 64) {
+        const int s = base + lane;
+        bool keep = false;
+        if (s < np) {
+            const double count = pid[s * kSkelStride + 19], total = pid[s * kSkelStride + 18];
+            keep = !(count < 2.0 || total / count < 0.45);
+        }
+        const unsigned long long m = __ballot(keep);
+        if (keep) {
+            const int r = n_out + __popcll(m & lanemask_lt());
+            if (r < PP_MAX_HUMANS) {
+                pp_human *hm = rec->humans + r;
+                for (int kp = 0; kp < PP_NUM_PART; kp++) {
+                    const int id = (int)pid[s * kSkelStride + kp];
+                    hm->peak_id[kp] = id;
+                    const bool ok = id >= 0 && id < n_peaks;
+                    hm->x[kp] = ok ? line_x[id] : 0;
+                    hm->y[kp] = ok ? line_y[id] : 0;
+                    hm->part_score[kp] = ok ? line_s[id] : 0.0f;
+                }
+                hm->score = (float)(pid[s * kSkelStride + 18] / pid[s * kSkelStride + 19]);
+                hm->n_parts = (int)pid[s * kSkelStride + 19];
+            }
+        }
+        n_out += __popcll(m);
+    }
+    if (lane == 0) {
+        if (n_out > PP_MAX_HUMANS) {
+            st |= PP_ST_HUMAN_OVERFLOW;
+            n_out = PP_MAX_HUMANS;
+        }
+        rec->n_humans = n_out;
+        rec->n_peaks = n_peaks;
+        rec->n_connections = s_coff[PP_NUM_LIMB];
+        rec->status = status[img] | st;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 size_t lds_bytes_heat(int elem, int h, int w, int maxp) {
     const size_t npix = (size_t)h * w;
@@ -1313,7 +1819,10 @@ hipError_t init_kernel_attributes() {
                          reinterpret_cast<const void *>(&k_limb_connect<__half>),
                          reinterpret_cast<const void *>(&k_limb_connect<float>),
                          reinterpret_cast<const void *>(&k_limb_connect_hwc),
-                         reinterpret_cast<const void *>(&k_assemble)};
+                         reinterpret_cast<const void *>(&k_assemble),
+                         reinterpret_cast<const void *>(&k_limb_connect_py<__half>),
+                         reinterpret_cast<const void *>(&k_limb_connect_py<float>),
+                         reinterpret_cast<const void *>(&k_assemble_py)};
     for (const void *f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
         if (e != hipSuccess) return e;
@@ -1370,6 +1879,34 @@ hipError_t launch_assemble(int batch, int maxp, int explicit_ids, const float4 *
     const size_t lds = lds_bytes_assemble(maxp);
     hipLaunchKernelGGL(k_assemble, dim3(batch), dim3(64), lds, stream, maxp, explicit_ids, peaks, counts, conns,
                        conn_counts, status, records);
+    return hipGetLastError();
+}
+
+size_t lds_bytes_limb_py(int elem, int h, int w, int maxp, int cap) {
+    return ((elem * (size_t)h * w + 15) & ~(size_t)15) + 64 + limb_lds_bytes_py(maxp, cap);
+}
+size_t lds_bytes_assemble_py(int maxp) { return assemble_py_lds_bytes(maxp); }
+
+hipError_t launch_limb_connect_py(const void *net, int dtype, int batch, int n_samples, int h, int w, int flip, int maxp,
+                                  int cap, int img_height, const int *img_height_dev, const float4 *peaks, const int *counts,
+                                  void *conns, int *conn_counts, unsigned *status, hipStream_t stream) {
+    const dim3 grid(PP_NUM_LIMB, batch), block(kThreads);
+    if (dtype == PP_F16) {
+        hipLaunchKernelGGL(k_limb_connect_py<__half>, grid, block, lds_bytes_limb_py(2, h, w, maxp, cap), stream,
+                           static_cast<const __half *>(net), n_samples, h, w, flip, maxp, cap, img_height, img_height_dev,
+                           peaks, counts, static_cast<double4 *>(conns), conn_counts, status);
+    } else {
+        hipLaunchKernelGGL(k_limb_connect_py<float>, grid, block, lds_bytes_limb_py(4, h, w, maxp, cap), stream,
+                           static_cast<const float *>(net), n_samples, h, w, flip, maxp, cap, img_height, img_height_dev,
+                           peaks, counts, static_cast<double4 *>(conns), conn_counts, status);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_assemble_py(int batch, int maxp, const float4 *peaks, const int *counts, const void *conns,
+                              const int *conn_counts, unsigned *status, pp_record *records, hipStream_t stream) {
+    hipLaunchKernelGGL(k_assemble_py, dim3(batch), dim3(64), lds_bytes_assemble_py(maxp), stream, maxp, peaks, counts,
+                       static_cast<const double4 *>(conns), conn_counts, status, records);
     return hipGetLastError();
 }
 

@@ -24,7 +24,7 @@ RECORD_DTYPE = np.dtype([("n_humans", "<i4"), ("n_peaks", "<i4"), ("status", "<u
 RECORD_BYTES = RECORD_DTYPE.itemsize
 
 EXPORTS = [
-    "pp_create", "pp_destroy", "pp_last_hip_error", "pp_status_string", "pp_device_available", "pp_process_batch",
+    "pp_create", "pp_destroy", "pp_last_hip_error", "pp_status_string", "pp_device_available", "pp_process_batch", "pp_process_batch_py",
     "pp_nms_batch", "pp_nms_batch_ex", "pp_time_kernels", "pp_bias_act_f16", "pp_maxpool2_f16", "pp_upsample2_f16", "pp_preprocess_u8", "pp_flip_average", "pp_pwconv_supported", "pp_pwconv_f16", "pp_debug_set_stamps", "pp_read_peaks", "pp_read_connections", "pp_read_records", "pp_process_paf_host",
     "pp_get_num_humans", "pp_get_part_peak_id", "pp_get_score", "pp_get_part_x", "pp_get_part_y",
     "pp_get_part_score", "pp_get_status",
@@ -71,6 +71,7 @@ def load():
     L.pp_status_string.argtypes = [C.c_int]
     L.pp_status_string.restype = C.c_char_p
     L.pp_process_batch.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]
+    L.pp_process_batch_py.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     L.pp_nms_batch.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     L.pp_nms_batch_ex.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, vp, vp, vp]
     L.pp_time_kernels.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp, vp]

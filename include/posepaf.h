@@ -101,6 +101,14 @@ PP_API int pp_device_available(void);
 PP_API int pp_process_batch(pp_ctx *ctx, int batch, const void *net_out_dev, int dtype, int h, int w, int flip,
                      int min_img_size, const int *min_img_size_dev, pp_record *records_dev, void *stream);
 
+/* The same batched path with the rules of the reference's PURE-PYTHON matching, find_connections + find_humans
+ * (utils/parse_skeletons.py:324-600) -- what evaluate.py runs with --run_refactor but WITHOUT --run_cpp.  It differs
+ * from the C++ rules in sampling (np.round(np.linspace)), float64 arithmetic, a stable sort, the merge conditions and the
+ * score bookkeeping.  img_height is find_connections' `img_height` argument.  Thresholds are the
+ * INI defaults (utils/config:17-25).  Needs max_peaks_per_part <= 64. */
+PP_API int pp_process_batch_py(pp_ctx *ctx, int batch, const void *net_out_dev, int dtype, int h, int w, int flip,
+                               int img_height, const int *img_height_dev, pp_record *records_dev, void *stream);
+
 /* Config-2 path: flip-average + NMS + refinement of the 18 keypoint channels only
  * (utils/parse_skeletons.py:126-176).  peaks_dev: DEVICE float[batch][18][max_peaks_per_part][4] =
  * (x, y, score, unused); counts_dev: DEVICE int[batch][18] (true counts, may exceed the capacity).

