@@ -24,6 +24,8 @@ struct pp_ctx {
     int *d_conn_counts = nullptr; // [max_batch][30]
     unsigned *d_status = nullptr; // [max_batch]
     void *d_conns_py = nullptr;   // [max_batch][30][maxp] double4 (src, dst, score, length): Python-twin path
+    double *d_persons = nullptr;  // [128][40] raw person table of the Python-twin host form
+    int *d_npersons = nullptr;
     pp_record *d_records = nullptr;  // [max_batch] (used when the caller passes NULL, and by the drop-in path)
     float *d_paf = nullptr;       // drop-in path: the caller's up-sampled (H,W,C) map
     size_t d_paf_bytes = 0;
@@ -59,6 +61,8 @@ void free_ctx(pp_ctx *c) {
     (void)hipFree(c->d_conn_counts);
     (void)hipFree(c->d_status);
     (void)hipFree(c->d_conns_py);
+    (void)hipFree(c->d_persons);
+    (void)hipFree(c->d_npersons);
     (void)hipFree(c->d_records);
     (void)hipFree(c->d_paf);
     delete c;
@@ -117,6 +121,8 @@ int pp_create(pp_ctx **out, int device, int max_batch, int max_h, int max_w, int
     if (e == hipSuccess) e = hipMalloc(&c->d_conns, B * PP_NUM_LIMB * c->maxp * sizeof(float4));
     if (e == hipSuccess) e = hipMalloc(&c->d_conn_counts, B * PP_NUM_LIMB * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&c->d_conns_py, B * PP_NUM_LIMB * c->maxp * 32);
+    if (e == hipSuccess) e = hipMalloc(&c->d_persons, 128 * 40 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&c->d_npersons, sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&c->d_status, B * sizeof(unsigned));
     if (e == hipSuccess) e = hipMalloc(&c->d_records, B * sizeof(pp_record));
     if (e == hipSuccess) e = hipMemset(c->d_counts, 0, B * PP_NUM_PART * sizeof(int));
@@ -207,8 +213,8 @@ int pp_process_batch_py(pp_ctx *ctx, int batch, const void *net_out_dev, int dty
     PP_HIP(ctx, pp::launch_limb_connect_py(net_out_dev, dtype, batch, ns, h, w, flip, ctx->maxp, ctx->cap, img_height,
                                            img_height_dev, ctx->d_peaks, ctx->d_counts, ctx->d_conns_py, ctx->d_conn_counts,
                                            ctx->d_status, st));
-    PP_HIP(ctx, pp::launch_assemble_py(batch, ctx->maxp, ctx->d_peaks, ctx->d_counts, ctx->d_conns_py, ctx->d_conn_counts,
-                                       ctx->d_status, rec, st));
+    PP_HIP(ctx, pp::launch_assemble_py(batch, ctx->maxp, 0, ctx->d_peaks, ctx->d_counts, ctx->d_conns_py, ctx->d_conn_counts,
+                                       ctx->d_status, rec, nullptr, nullptr, st));
     ctx->last_stream = st;
     ctx->last_batch = batch;
     ctx->last_peaks = ctx->d_peaks;
@@ -399,6 +405,124 @@ float pp_get_part_score(const pp_ctx *ctx, int cid) {
     return (ctx && cid >= 0 && cid < (int)ctx->line_s.size()) ? ctx->line_s[cid] : 0.0f;
 }
 uint32_t pp_get_status(const pp_ctx *ctx) { return (ctx && ctx->have_result) ? ctx->h_record.status : 0u; }
+
+// ------------------------------------------------------------------------------------------------ Python twins, host form
+namespace {
+// all_peaks[k] in input order (what find_connections indexes with i / j); rows keep their own id (column 3)
+int bucket_py(const pp_ctx *ctx, const float *peaks, int n, std::vector<float4> &pk, int counts[PP_NUM_PART]) {
+    const int maxp = ctx->maxp;
+    pk.assign((size_t)PP_NUM_PART * maxp, float4{0, 0, 0, 0});
+    for (int k = 0; k < PP_NUM_PART; k++) counts[k] = 0;
+    for (int i = 0; i < n; i++) {
+        const float *r = peaks + (size_t)5 * i;
+        const int part = (int)r[4];
+        if (part < 0 || part >= PP_NUM_PART) return PP_ERR_BAD_ARG;
+        if (counts[part] >= maxp) return PP_ERR_OVERFLOW;
+        float4 v;
+        v.x = r[0];
+        v.y = r[1];
+        v.z = r[2];
+        v.w = r[3];  // id as given (a float in the joint list)
+        pk[(size_t)part * maxp + counts[part]++] = v;
+    }
+    return PP_OK;
+}
+}  // namespace
+
+int pp_py_find_connections_host(pp_ctx *ctx, const float *peaks, int n, const float *paf, int H, int W, int C, int img_height,
+                                double *conns_out, int *counts_out, int *special_out) {
+    if (!ctx || !peaks || !paf || !conns_out || !counts_out || n < 0 || H <= 0 || W <= 0 || C <= 0) return PP_ERR_BAD_ARG;
+    if (pp::lds_bytes_assemble_py(ctx->maxp) > pp::kMaxDynLds) return PP_ERR_TOO_LARGE;
+    std::vector<float4> pk;
+    int counts[PP_NUM_PART];
+    int rc = bucket_py(ctx, peaks, n, pk, counts);
+    if (rc != PP_OK) return rc;
+    const int maxp = ctx->maxp;
+    PP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t paf_bytes = sizeof(float) * (size_t)H * W * C;
+    if (paf_bytes > ctx->d_paf_bytes) {
+        if (ctx->d_paf) (void)hipFree(ctx->d_paf);
+        ctx->d_paf = nullptr;
+        ctx->d_paf_bytes = 0;
+        PP_HIP(ctx, hipMalloc(&ctx->d_paf, paf_bytes));
+        ctx->d_paf_bytes = paf_bytes;
+    }
+    hipStream_t st = nullptr;
+    PP_HIP(ctx, hipMemcpyAsync(ctx->d_paf, paf, paf_bytes, hipMemcpyHostToDevice, st));
+    PP_HIP(ctx, hipMemcpyAsync(ctx->d_peaks, pk.data(), pk.size() * sizeof(float4), hipMemcpyHostToDevice, st));
+    PP_HIP(ctx, hipMemcpyAsync(ctx->d_counts, counts, sizeof(counts), hipMemcpyHostToDevice, st));
+    PP_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(unsigned), st));
+    PP_HIP(ctx, pp::launch_limb_connect_py_hwc(ctx->d_paf, H, W, C, maxp, ctx->cap, img_height, ctx->d_peaks, ctx->d_counts,
+                                               ctx->d_conns_py, ctx->d_conn_counts, ctx->d_status, st));
+    std::vector<double> raw((size_t)PP_NUM_LIMB * maxp * 4);
+    PP_HIP(ctx, hipMemcpyAsync(raw.data(), ctx->d_conns_py, raw.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    PP_HIP(ctx, hipMemcpyAsync(counts_out, ctx->d_conn_counts, sizeof(int) * PP_NUM_LIMB, hipMemcpyDeviceToHost, st));
+    unsigned status = 0;
+    PP_HIP(ctx, hipMemcpyAsync(&status, ctx->d_status, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    PP_HIP(ctx, hipStreamSynchronize(st));
+    if (status & PP_ST_CAND_OVERFLOW) return PP_ERR_OVERFLOW;
+    static const int LP[PP_NUM_LIMB][2] = {{1, 0},   {1, 14},  {1, 15},  {1, 16},  {1, 17},  {0, 14},  {0, 15},  {14, 16},
+                                           {15, 17}, {1, 2},   {2, 3},   {3, 4},   {1, 5},   {5, 6},   {6, 7},   {1, 8},
+                                           {8, 9},   {9, 10},  {1, 11},  {11, 12}, {12, 13}, {0, 2},   {0, 5},   {2, 8},
+                                           {8, 12},  {5, 11},  {11, 9},  {16, 2},  {17, 5},  {8, 11}};
+    for (int limb = 0; limb < PP_NUM_LIMB; limb++) {
+        const int pa = LP[limb][0], pb = LP[limb][1];
+        if (special_out) special_out[limb] = (counts[pa] == 0 && counts[pb] == 0) ? 1 : 0;  // parse_skeletons.py:340-342
+        for (int k = 0; k < counts_out[limb]; k++) {
+            const double *r = raw.data() + ((size_t)limb * maxp + k) * 4;
+            double *o = conns_out + ((size_t)limb * maxp + k) * 6;
+            const int i = (int)r[0], j = (int)r[1];
+            o[0] = (double)pk[(size_t)pa * maxp + i].w;  // joints_src[i][3]
+            o[1] = (double)pk[(size_t)pb * maxp + j].w;
+            o[2] = r[2];
+            o[3] = (double)i;
+            o[4] = (double)j;
+            o[5] = r[3];
+        }
+    }
+    return PP_OK;
+}
+
+int pp_py_find_humans_host(pp_ctx *ctx, const double *conns, const int *counts_limb, const float *peaks, int n,
+                           double *persons_out, int cap, int *n_out) {
+    if (!ctx || !conns || !counts_limb || !peaks || !persons_out || !n_out || n < 0 || cap <= 0) return PP_ERR_BAD_ARG;
+    if (pp::lds_bytes_assemble_py(ctx->maxp) > pp::kMaxDynLds) return PP_ERR_TOO_LARGE;
+    std::vector<float4> pk;
+    int counts[PP_NUM_PART];
+    int rc = bucket_py(ctx, peaks, n, pk, counts);
+    if (rc != PP_OK) return rc;
+    const int maxp = ctx->maxp;
+    std::vector<double> raw((size_t)PP_NUM_LIMB * maxp * 4, 0.0);
+    int cl[PP_NUM_LIMB];
+    for (int limb = 0; limb < PP_NUM_LIMB; limb++) {
+        cl[limb] = counts_limb[limb];
+        if (cl[limb] < 0 || cl[limb] > maxp) return PP_ERR_BAD_ARG;
+        for (int k = 0; k < cl[limb]; k++) {
+            const double *i6 = conns + ((size_t)limb * maxp + k) * 6;
+            double *r = raw.data() + ((size_t)limb * maxp + k) * 4;
+            r[0] = i6[0];  // src peak id
+            r[1] = i6[1];  // dst peak id
+            r[2] = i6[2];
+            r[3] = i6[5];
+        }
+    }
+    PP_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = nullptr;
+    PP_HIP(ctx, hipMemcpyAsync(ctx->d_peaks, pk.data(), pk.size() * sizeof(float4), hipMemcpyHostToDevice, st));
+    PP_HIP(ctx, hipMemcpyAsync(ctx->d_counts, counts, sizeof(counts), hipMemcpyHostToDevice, st));
+    PP_HIP(ctx, hipMemcpyAsync(ctx->d_conns_py, raw.data(), raw.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    PP_HIP(ctx, hipMemcpyAsync(ctx->d_conn_counts, cl, sizeof(cl), hipMemcpyHostToDevice, st));
+    PP_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(unsigned), st));
+    PP_HIP(ctx, pp::launch_assemble_py(1, maxp, 1, ctx->d_peaks, ctx->d_counts, ctx->d_conns_py, ctx->d_conn_counts,
+                                       ctx->d_status, ctx->d_records, ctx->d_persons, ctx->d_npersons, st));
+    int np = 0;
+    PP_HIP(ctx, hipMemcpyAsync(&np, ctx->d_npersons, sizeof(int), hipMemcpyDeviceToHost, st));
+    PP_HIP(ctx, hipStreamSynchronize(st));
+    if (np > 128 || np > cap) return PP_ERR_OVERFLOW;
+    PP_HIP(ctx, hipMemcpy(persons_out, ctx->d_persons, sizeof(double) * 40 * (size_t)np, hipMemcpyDeviceToHost));
+    *n_out = np;
+    return PP_OK;
+}
 
 // ---- the reference's seven names, one process-wide context (pafprocess.cpp:16-17 keeps globals too)
 static pp_ctx *g_ctx = nullptr;

@@ -37,8 +37,12 @@ size_t lds_bytes_assemble_py(int maxp);
 hipError_t launch_limb_connect_py(const void *net, int dtype, int batch, int n_samples, int h, int w, int flip, int maxp,
                                   int cap, int img_height, const int *img_height_dev, const float4 *peaks, const int *counts,
                                   void *conns, int *conn_counts, unsigned *status, hipStream_t stream);
-hipError_t launch_assemble_py(int batch, int maxp, const float4 *peaks, const int *counts, const void *conns,
-                              const int *conn_counts, unsigned *status, pp_record *records, hipStream_t stream);
+hipError_t launch_assemble_py(int batch, int maxp, int explicit_ids, const float4 *peaks, const int *counts, const void *conns,
+                              const int *conn_counts, unsigned *status, pp_record *records, double *persons_out,
+                              int *n_persons_out, hipStream_t stream);
+hipError_t launch_limb_connect_py_hwc(const float *paf, int H, int W, int C, int maxp, int cap, int img_height,
+                                      const float4 *peaks, const int *counts, void *conns, int *conn_counts, unsigned *status,
+                                      hipStream_t stream);
 
 }  // namespace pp
 #endif

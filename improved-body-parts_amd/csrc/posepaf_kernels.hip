@@ -1398,62 +1398,12 @@ __device__ bool score_pair_py(const Sampler &smp, float axf, float ayf, float as
     return true;
 }
 
-// LDS (dynamic): [map h*w T][cubic 16 f32][LimbLdsPy]
-template <typename T>
-__global__ __launch_bounds__(kThreads) void k_limb_connect_py(const T *__restrict__ net, int n_samples, int h, int w,
-                                                              int flip, int maxp, int cap, int img_height,
-                                                              const int *__restrict__ img_height_dev,
-                                                              const float4 *__restrict__ peaks,
-                                                              const int *__restrict__ counts, double4 *__restrict__ conns,
-                                                              int *__restrict__ conn_counts,
-                                                              unsigned *__restrict__ status) {
-    extern __shared__ __align__(16) unsigned char lds_raw[];
+// pafprocess-free Python rules for one limb: scoring, stable ranking, greedy pick, ordered output
+template <typename Sampler>
+__device__ void connect_limb_py(const Sampler &smp, const LimbLdsPy &L, int nA, int nB, int cap, int maxp, int ih,
+                                double4 *__restrict__ conn_out, int *__restrict__ cc, unsigned *__restrict__ status_word) {
     __shared__ int s_wcnt[2][kWaves];
-    const int limb = blockIdx.x, img = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int pa = d_limb_pairs[limb][0], pb = d_limb_pairs[limb][1];
-    int nA = counts[img * PP_NUM_PART + pa], nB = counts[img * PP_NUM_PART + pb];
-    nA = nA < maxp ? nA : maxp;
-    nB = nB < maxp ? nB : maxp;
-    int *cc = conn_counts + img * PP_NUM_LIMB + limb;
-    if (nA == 0 || nB == 0) {
-        if (threadIdx.x == 0) *cc = 0;
-        return;
-    }
-    const int npix = h * w;
-    size_t off = 0;
-    T *smap = reinterpret_cast<T *>(lds_raw);
-    off += (sizeof(T) * (size_t)npix + 15) & ~(size_t)15;
-    float *s_cub = reinterpret_cast<float *>(lds_raw + off);
-    off += 64;
-    LimbLdsPy L = carve_limb_lds_py(lds_raw + off, maxp, cap);
-    if (threadIdx.x < 16) s_cub[threadIdx.x] = d_cubic4[threadIdx.x >> 2][threadIdx.x & 3];
-    const float4 *pka = peaks + ((size_t)img * PP_NUM_PART + pa) * maxp;
-    const float4 *pkb = peaks + ((size_t)img * PP_NUM_PART + pb) * maxp;
-    for (int i = threadIdx.x; i < nA; i += kThreads) {
-        const float4 p = pka[i];
-        L.ax[i] = p.x;
-        L.ay[i] = p.y;
-        L.as[i] = p.z;
-    }
-    for (int i = threadIdx.x; i < nB; i += kThreads) {
-        const float4 p = pkb[i];
-        L.bx[i] = p.x;
-        L.by[i] = p.y;
-        L.bs[i] = p.z;
-    }
-    for (int i = threadIdx.x; i < maxp; i += kThreads) {
-        L.usedA[i] = 0;
-        L.usedB[i] = 0;
-    }
-    const size_t plane = (size_t)npix;
-    const T *o0 = net + ((size_t)img * n_samples * PP_NUM_CH + limb) * plane;
-    const T *o1 = net + (((size_t)img * n_samples + 1) * PP_NUM_CH + d_flip_paf_ord[limb]) * plane;
-    load_channel(smap, o0, o1, h, w, flip != 0);
-    __syncthreads();
-    LdsBicubicSampler<T> smp{smap, s_cub, h, w};
-    const int ih = img_height_dev ? img_height_dev[img] : img_height;
-
     // ---- scoring + ordered compaction (generation order: src outer, dst inner)
     const int npairs = nA * nB;
     int ncand = 0, buf = 0;
@@ -1545,7 +1495,6 @@ __global__ __launch_bounds__(kThreads) void k_limb_connect_py(const T *__restric
         }
         __syncthreads();
     }
-    double4 *conn_out = conns + ((size_t)img * PP_NUM_LIMB + limb) * maxp;
     int ncn = 0;
     for (int base = 0; base < n; base += kThreads, buf ^= 1) {
         const int r = base + threadIdx.x;
@@ -1574,8 +1523,105 @@ __global__ __launch_bounds__(kThreads) void k_limb_connect_py(const T *__restric
     }
     if (threadIdx.x == 0) {
         *cc = ncn;
-        if (st) atomicOr(status + img, st);
+        if (st) atomicOr(status_word, st);
     }
+}
+
+// LDS (dynamic): [map h*w T][cubic 16 f32][LimbLdsPy]
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_limb_connect_py(const T *__restrict__ net, int n_samples, int h, int w,
+                                                              int flip, int maxp, int cap, int img_height,
+                                                              const int *__restrict__ img_height_dev,
+                                                              const float4 *__restrict__ peaks,
+                                                              const int *__restrict__ counts, double4 *__restrict__ conns,
+                                                              int *__restrict__ conn_counts,
+                                                              unsigned *__restrict__ status) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int limb = blockIdx.x, img = blockIdx.y;
+    const int pa = d_limb_pairs[limb][0], pb = d_limb_pairs[limb][1];
+    int nA = counts[img * PP_NUM_PART + pa], nB = counts[img * PP_NUM_PART + pb];
+    nA = nA < maxp ? nA : maxp;
+    nB = nB < maxp ? nB : maxp;
+    int *cc = conn_counts + img * PP_NUM_LIMB + limb;
+    if (nA == 0 || nB == 0) {
+        if (threadIdx.x == 0) *cc = 0;
+        return;
+    }
+    const int npix = h * w;
+    size_t off = 0;
+    T *smap = reinterpret_cast<T *>(lds_raw);
+    off += (sizeof(T) * (size_t)npix + 15) & ~(size_t)15;
+    float *s_cub = reinterpret_cast<float *>(lds_raw + off);
+    off += 64;
+    LimbLdsPy L = carve_limb_lds_py(lds_raw + off, maxp, cap);
+    if (threadIdx.x < 16) s_cub[threadIdx.x] = d_cubic4[threadIdx.x >> 2][threadIdx.x & 3];
+    const float4 *pka = peaks + ((size_t)img * PP_NUM_PART + pa) * maxp;
+    const float4 *pkb = peaks + ((size_t)img * PP_NUM_PART + pb) * maxp;
+    for (int i = threadIdx.x; i < nA; i += kThreads) {
+        const float4 p = pka[i];
+        L.ax[i] = p.x;
+        L.ay[i] = p.y;
+        L.as[i] = p.z;
+    }
+    for (int i = threadIdx.x; i < nB; i += kThreads) {
+        const float4 p = pkb[i];
+        L.bx[i] = p.x;
+        L.by[i] = p.y;
+        L.bs[i] = p.z;
+    }
+    for (int i = threadIdx.x; i < maxp; i += kThreads) {
+        L.usedA[i] = 0;
+        L.usedB[i] = 0;
+    }
+    const size_t plane = (size_t)npix;
+    const T *o0 = net + ((size_t)img * n_samples * PP_NUM_CH + limb) * plane;
+    const T *o1 = net + (((size_t)img * n_samples + 1) * PP_NUM_CH + d_flip_paf_ord[limb]) * plane;
+    load_channel(smap, o0, o1, h, w, flip != 0);
+    __syncthreads();
+    LdsBicubicSampler<T> smp{smap, s_cub, h, w};
+    const int ih = img_height_dev ? img_height_dev[img] : img_height;
+
+    connect_limb_py(smp, L, nA, nB, cap, maxp, ih, conns + ((size_t)img * PP_NUM_LIMB + limb) * maxp, cc, status + img);
+}
+
+// Host-array form (utils.parse_skeletons.find_connections): the caller's up-sampled (H, W, C) map in global memory
+__global__ __launch_bounds__(kThreads) void k_limb_connect_py_hwc(const float *__restrict__ paf, int H, int W, int C, int maxp,
+                                                                  int cap, int img_height, const float4 *__restrict__ peaks,
+                                                                  const int *__restrict__ counts, double4 *__restrict__ conns,
+                                                                  int *__restrict__ conn_counts, unsigned *__restrict__ status) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int limb = blockIdx.x;
+    const int pa = d_limb_pairs[limb][0], pb = d_limb_pairs[limb][1];
+    int nA = counts[pa], nB = counts[pb];
+    nA = nA < maxp ? nA : maxp;
+    nB = nB < maxp ? nB : maxp;
+    int *cc = conn_counts + limb;
+    if (nA == 0 || nB == 0 || limb >= C) {
+        if (threadIdx.x == 0) *cc = 0;
+        return;
+    }
+    LimbLdsPy L = carve_limb_lds_py(lds_raw, maxp, cap);
+    const float4 *pka = peaks + (size_t)pa * maxp;
+    const float4 *pkb = peaks + (size_t)pb * maxp;
+    for (int i = threadIdx.x; i < nA; i += kThreads) {
+        const float4 p = pka[i];
+        L.ax[i] = p.x;
+        L.ay[i] = p.y;
+        L.as[i] = p.z;
+    }
+    for (int i = threadIdx.x; i < nB; i += kThreads) {
+        const float4 p = pkb[i];
+        L.bx[i] = p.x;
+        L.by[i] = p.y;
+        L.bs[i] = p.z;
+    }
+    for (int i = threadIdx.x; i < maxp; i += kThreads) {
+        L.usedA[i] = 0;
+        L.usedB[i] = 0;
+    }
+    __syncthreads();
+    GlobalHwcSampler smp{paf, H, W, C, limb};
+    connect_limb_py(smp, L, nA, nB, cap, maxp, img_height, conns + (size_t)limb * maxp, cc, status);
 }
 
 // find_humans, one wave per image, float64 person table in LDS: [s][k] = {id, score}; k = 18: {total, -1}; 19: {count, len}
@@ -1584,9 +1630,11 @@ __host__ __device__ inline size_t assemble_py_lds_bytes(int maxp) {
     return (size_t)kMaxSkelPy * kSkelStride * 16 + (size_t)PP_NUM_PART * maxp * 16 + (size_t)PP_NUM_LIMB * maxp * 32;
 }
 
-__global__ __launch_bounds__(64) void k_assemble_py(int maxp, const float4 *__restrict__ peaks, const int *__restrict__ counts,
-                                                    const double4 *__restrict__ conns, const int *__restrict__ conn_counts,
-                                                    unsigned *__restrict__ status, pp_record *__restrict__ records) {
+__global__ __launch_bounds__(64) void k_assemble_py(int maxp, int explicit_ids, const float4 *__restrict__ peaks,
+                                                    const int *__restrict__ counts, const double4 *__restrict__ conns,
+                                                    const int *__restrict__ conn_counts, unsigned *__restrict__ status,
+                                                    pp_record *__restrict__ records, double *__restrict__ persons_out,
+                                                    int *__restrict__ n_persons_out) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int img = blockIdx.x, lane = threadIdx.x;
     const int ntab = PP_NUM_PART * maxp;
@@ -1638,8 +1686,10 @@ __global__ __launch_bounds__(64) void k_assemble_py(int maxp, const float4 *__re
         const double4 *cn_g = conns + ((size_t)img * PP_NUM_LIMB + limb) * maxp;
         for (int ci = lane; ci < c; ci += 64) {
             double4 cn = cn_g[ci];
-            cn.x = (double)(s_off[part1] + (int)cn.x);  // peak id == position in the part-ordered joint list
-            cn.y = (double)(s_off[part2] + (int)cn.y);
+            if (!explicit_ids) {  // peak id == position in the part-ordered joint list
+                cn.x = (double)(s_off[part1] + (int)cn.x);
+                cn.y = (double)(s_off[part2] + (int)cn.y);
+            }
             s_conn[o + ci] = cn;
         }
     }
@@ -1670,7 +1720,9 @@ __global__ __launch_bounds__(64) void k_assemble_py(int maxp, const float4 *__re
                 }
             }
             if (num_found > 2) num_found = 2;
-            const double ps_src = (double)line_s[(int)src_id], ps_dst = (double)line_s[(int)dst_id];
+            const int isrc = (int)src_id, idst = (int)dst_id;  // joint_candidates[int(id), 2]: indexed BY ID (:474, :589)
+            const double ps_src = (isrc >= 0 && isrc < n_peaks) ? (double)line_s[isrc] : 0.0;
+            const double ps_dst = (idst >= 0 && idst < n_peaks) ? (double)line_s[idst] : 0.0;
             if (num_found == 1) {  // :452-487
                 if (lane == 0) {
                     double *i1 = pid + idx1 * kSkelStride, *f1 = psc + idx1 * kSkelStride;
@@ -1779,9 +1831,17 @@ __global__ __launch_bounds__(64) void k_assemble_py(int maxp, const float4 *__re
                 hm->score = (float)(pid[s * kSkelStride + 18] / pid[s * kSkelStride + 19]);
                 hm->n_parts = (int)pid[s * kSkelStride + 19];
             }
+            if (persons_out) {  // raw person_to_joint_assoc rows (20, 2) float64
+                double *row = persons_out + (size_t)r * 40;
+                for (int k = 0; k < 20; k++) {
+                    row[2 * k] = pid[s * kSkelStride + k];
+                    row[2 * k + 1] = psc[s * kSkelStride + k];
+                }
+            }
         }
         n_out += __popcll(m);
     }
+    if (lane == 0 && n_persons_out) *n_persons_out = n_out;
     if (lane == 0) {
         if (n_out > PP_MAX_HUMANS) {
             st |= PP_ST_HUMAN_OVERFLOW;
@@ -1822,6 +1882,7 @@ hipError_t init_kernel_attributes() {
                          reinterpret_cast<const void *>(&k_assemble),
                          reinterpret_cast<const void *>(&k_limb_connect_py<__half>),
                          reinterpret_cast<const void *>(&k_limb_connect_py<float>),
+                         reinterpret_cast<const void *>(&k_limb_connect_py_hwc),
                          reinterpret_cast<const void *>(&k_assemble_py)};
     for (const void *f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
@@ -1903,10 +1964,19 @@ hipError_t launch_limb_connect_py(const void *net, int dtype, int batch, int n_s
     return hipGetLastError();
 }
 
-hipError_t launch_assemble_py(int batch, int maxp, const float4 *peaks, const int *counts, const void *conns,
-                              const int *conn_counts, unsigned *status, pp_record *records, hipStream_t stream) {
-    hipLaunchKernelGGL(k_assemble_py, dim3(batch), dim3(64), lds_bytes_assemble_py(maxp), stream, maxp, peaks, counts,
-                       static_cast<const double4 *>(conns), conn_counts, status, records);
+hipError_t launch_assemble_py(int batch, int maxp, int explicit_ids, const float4 *peaks, const int *counts, const void *conns,
+                              const int *conn_counts, unsigned *status, pp_record *records, double *persons_out,
+                              int *n_persons_out, hipStream_t stream) {
+    hipLaunchKernelGGL(k_assemble_py, dim3(batch), dim3(64), lds_bytes_assemble_py(maxp), stream, maxp, explicit_ids, peaks,
+                       counts, static_cast<const double4 *>(conns), conn_counts, status, records, persons_out, n_persons_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_limb_connect_py_hwc(const float *paf, int H, int W, int C, int maxp, int cap, int img_height,
+                                      const float4 *peaks, const int *counts, void *conns, int *conn_counts, unsigned *status,
+                                      hipStream_t stream) {
+    hipLaunchKernelGGL(k_limb_connect_py_hwc, dim3(PP_NUM_LIMB), dim3(kThreads), limb_lds_bytes_py(maxp, cap), stream, paf, H,
+                       W, C, maxp, cap, img_height, peaks, counts, static_cast<double4 *>(conns), conn_counts, status);
     return hipGetLastError();
 }
 

@@ -8,9 +8,11 @@ All three run on the GPU (pre-processing kernel -> model -> pp_flip_average / pp
 inputs/outputs the reference's signatures prescribe.  For throughput use posepaf.pipeline.PosePipeline, which keeps the
 network output in HBM and never builds these intermediate arrays.
 
-`find_connections` / `find_humans` (the pure-Python twins, :324-600) follow DIFFERENT rules from the C++ `pafprocess`
-path this repository reproduces; they are not provided yet and raise NotImplementedError pointing
-at utils.pafprocess.
+    find_connections(all_peaks, paf_avg, img_height, test_cfg, joint2limb_pairs) -> (connected_limbs, special_limb)  :324-410
+    find_humans(connected_limbs, special_limb, joint_list, test_cfg, joint2limb_pairs) -> (persons, candidates)     :413-600
+
+The last two are the pure-Python twins, whose rules differ from the C++ `pafprocess` path; both
+rule sets are implemented as kernels.
 """
 import ctypes as C
 
@@ -94,11 +96,72 @@ def find_peaks_refactor(param, img):
     return np.rint(xy).astype(np.intp)
 
 
-def find_connections(*args, **kwargs):
-    raise NotImplementedError("the pure-Python matching (parse_skeletons.py:324-410) is not reproduced; use "
-                              "utils.pafprocess.pafprocess.process_paf (C++ semantics) or posepaf.api.PosePostProcessor")
+_ini = sk.default_test_cfg()
 
 
-def find_humans(*args, **kwargs):
-    raise NotImplementedError("the pure-Python assembly (parse_skeletons.py:413-600) is not reproduced; use "
-                              "utils.pafprocess.pafprocess.process_paf (C++ semantics) or posepaf.api.PosePostProcessor")
+def _check_cfg(test_cfg):
+    for k in ("thre2", "connect_ration", "mid_num", "len_rate", "connection_tole"):
+        if k in test_cfg and float(test_cfg[k]) != float(_ini[k]):
+            raise NotImplementedError(f"test_cfg[{k!r}] = {test_cfg[k]}: only the INI defaults (utils/config:17-25) are built in")
+    if int(test_cfg.get("remove_recon", 0)) != 0:
+        raise NotImplementedError("remove_recon != 0 is not supported (reference default 0)")
+
+
+def _joint_rows(all_peaks):
+    rows = [tuple(float(v) for v in pk[:4]) + (float(part),) for part, pks in enumerate(all_peaks) for pk in pks]
+    return np.asarray(rows, np.float32).reshape(-1, 5)
+
+
+def _ctx():
+    """context for the host-form twins: 64 peaks per part (the float64 person table + connections must fit LDS)"""
+    from posepaf.api import PosePostProcessor
+    if "py" not in _post_cache:
+        _post_cache["py"] = PosePostProcessor(max_batch=1, max_h=sk.BOXSIZE // sk.STRIDE, max_w=sk.BOXSIZE // sk.STRIDE,
+                                              max_peaks_per_part=64)
+    return _post_cache["py"]
+
+
+def find_connections(all_peaks, paf_avg, img_height, test_cfg, joint2limb_pairs):
+    """utils/parse_skeletons.py:324-410 on the GPU (k_limb_connect_py_hwc): -> (connected_limbs, special_limb) with
+    connected_limbs[k] an (n, 6) float64 array [src_peak_id, dst_peak_id, score, i, j, limb_len] ([] for special limbs)."""
+    _check_cfg(test_cfg)
+    if [tuple(p) for p in np.asarray(joint2limb_pairs).tolist()] != [tuple(p) for p in sk.LIMB_PAIRS]:
+        raise NotImplementedError("joint2limb_pairs must be the canonical 30 limbs (config/config.py:114-121)")
+    post = _ctx()
+    jl = _joint_rows(all_peaks)
+    paf = np.ascontiguousarray(paf_avg, dtype=np.float32)
+    conns = np.zeros((NUM_PAFS, post.maxp, 6), np.float64)
+    counts = np.zeros(NUM_PAFS, np.int32)
+    special = np.zeros(NUM_PAFS, np.int32)
+    L = _lib.load()
+    _lib.check(L.pp_py_find_connections_host(post.ctx, jl.ctypes.data_as(C.POINTER(C.c_float)), len(jl),
+                                             paf.ctypes.data_as(C.POINTER(C.c_float)), paf.shape[0], paf.shape[1], paf.shape[2],
+                                             int(img_height), conns.ctypes.data_as(C.POINTER(C.c_double)),
+                                             counts.ctypes.data_as(C.POINTER(C.c_int)), special.ctypes.data_as(C.POINTER(C.c_int))),
+               post.ctx)
+    connected = [[] if special[k] else conns[k, :counts[k]].copy() for k in range(NUM_PAFS)]
+    return connected, [int(k) for k in np.nonzero(special)[0]]
+
+
+def find_humans(connected_limbs, special_limb, joint_list, test_cfg, joint2limb_pairs):
+    """utils/parse_skeletons.py:413-600 on the GPU (k_assemble_py): -> (person_to_joint_assoc (P, 20, 2) float64,
+    joint_candidates (N, 4) float64)."""
+    _check_cfg(test_cfg)
+    post = _ctx()
+    jl = _joint_rows(joint_list)
+    conns = np.zeros((NUM_PAFS, post.maxp, 6), np.float64)
+    counts = np.zeros(NUM_PAFS, np.int32)
+    for k in range(NUM_PAFS):
+        if k in special_limb or len(connected_limbs[k]) == 0:
+            continue
+        c = np.asarray(connected_limbs[k], np.float64).reshape(-1, 6)
+        counts[k] = len(c)
+        conns[k, :len(c)] = c
+    persons = np.zeros((128, 20, 2), np.float64)
+    n = C.c_int(0)
+    L = _lib.load()
+    _lib.check(L.pp_py_find_humans_host(post.ctx, conns.ctypes.data_as(C.POINTER(C.c_double)),
+                                        counts.ctypes.data_as(C.POINTER(C.c_int)), jl.ctypes.data_as(C.POINTER(C.c_float)), len(jl),
+                                        persons.ctypes.data_as(C.POINTER(C.c_double)), 128, C.byref(n)), post.ctx)
+    joint_candidates = np.array([item for sublist in joint_list for item in sublist], dtype=np.float64).reshape(-1, 4)
+    return persons[: n.value].copy(), joint_candidates

@@ -189,6 +189,16 @@ PP_API int pp_get_part_y(const pp_ctx *ctx, int cid);
 PP_API float pp_get_part_score(const pp_ctx *ctx, int cid);
 PP_API uint32_t pp_get_status(const pp_ctx *ctx);
 
+/* ---------------------------------------------------------------- Python twins, host form
+ * utils.parse_skeletons.find_connections / find_humans (:324-600) with host arrays, for callers of the non --run_cpp
+ * branch of evaluate.py (:88-89).  peaks: joint-list rows [x, y, score, id, part] (n of them); paf: (H, W, C) float32.
+ * conns: double[30][max_peaks_per_part][6] rows {src_id, dst_id, score, i, j, limb_len}; counts: int[30];
+ * special: int[30] (1 where neither part has a peak); persons: rows of 40 doubles = person_to_joint_assoc (20, 2). */
+PP_API int pp_py_find_connections_host(pp_ctx *ctx, const float *peaks, int n, const float *paf, int H, int W, int C,
+                                       int img_height, double *conns_out, int *counts_out, int *special_out);
+PP_API int pp_py_find_humans_host(pp_ctx *ctx, const double *conns, const int *counts, const float *peaks, int n,
+                                  double *persons_out, int cap, int *n_out);
+
 /* ---------------------------------------------------------------- drop-in, reference names
  * Replaces /root/reference/utils/pafprocess/pafprocess.h:70-76 one for one.
  *   peaks  : host float[p1][p2][p3], rows [x, y, score, peak_id, part]   (evaluate.py:99-107, p3 = 5)

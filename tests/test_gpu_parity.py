@@ -244,8 +244,29 @@ def test_reference_shaped_parse_skeletons_surface(torch_cuda, oracle):
         out = model(preprocess_batch(torch_cuda.from_numpy(img).cuda()[None], True, torch_cuda.float16)).cpu().numpy()
     hh, pp = oracle.flip_average(out)
     assert np.allclose(h_, hh.transpose(1, 2, 0), atol=2e-2) and np.allclose(p_, pp.transpose(1, 2, 0), atol=2e-2)
+
+
+@pytest.mark.parametrize("key", ["P2_s1_f16", "P6_s2_f32", "P15_s0_f16", "P30_s2_f32"])
+def test_find_connections_find_humans_host_surface(torch_cuda, oracle, key):
+    """utils.parse_skeletons.find_connections / find_humans (reference signatures, kernels inside) against the
+    reference's own Python output (golden G3), in float64."""
+    from posepaf import skeleton as sk
+    from utils import parse_skeletons as ps
+    net, g = load_scene(key)
+    _, paf = oracle.flip_average(net)
+    up = oracle.upsample4_hwc(paf)
+    jl = g["joint_list"]
+    all_peaks = [[tuple(float(v) for v in row[:4]) for row in jl[jl[:, 4] == k]] for k in range(18)]
+    cfg = sk.default_test_cfg()
+    connected, special = ps.find_connections(all_peaks, up, 512, cfg, np.array(sk.LIMB_PAIRS))
+    assert np.array_equal(np.array([len(c) for c in connected], np.int32), g["py_n_connections"])
+    persons, cand = ps.find_humans(connected, special, all_peaks, cfg, np.array(sk.LIMB_PAIRS))
+    want = g["py_persons"]
+    assert persons.shape == want.shape and cand.shape == (len(jl), 4)
+    assert np.array_equal(persons[:, :, 0], want[:, :, 0])              # ids, totals, counts: exact
+    assert np.allclose(persons[:, :, 1], want[:, :, 1], rtol=0, atol=1e-9)
     with pytest.raises(NotImplementedError):
-        ps.find_connections()
+        ps.find_connections(all_peaks, up, 512, dict(cfg, thre2=0.05), np.array(sk.LIMB_PAIRS))
 
 
 def test_original_path_nms_and_centroid_modes(torch_cuda, oracle):
