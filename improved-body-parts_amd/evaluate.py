@@ -4,8 +4,8 @@
     python evaluate.py --run_refactor --run_cpp --synthetic 64 [--batch 16] [--dump_name results.json]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 evaluate.py --synthetic 5000 ...
 
-What is kept from the reference: the flags --run_refactor / --run_cpp (:53-54; this build only implements that
-combination, the README's 65.8-AP / 7.3-fps row), the per-image result format (append_result :182-209) and the
+What is kept from the reference: the flags --run_refactor / --run_cpp (:53-54; --run_refactor is required, --run_cpp
+selects the C++ pafprocess rules -- the README's 65.8-AP / 7.3-fps row -- and its absence the pure-Python rules), the per-image result format (append_result :182-209) and the
 COCO-style JSON dump (:269-270).  What changes: images are processed in batches, sharded i mod W over the ranks, with one
 RCCL all-gather of the fixed-size records; nothing is copied to the host before the final records.
 
@@ -48,8 +48,8 @@ def parse():
 
 def main():
     a = parse()
-    if not (a.run_refactor and a.run_cpp):
-        raise SystemExit("only --run_refactor --run_cpp (the C++-pafprocess semantics) is implemented on this path")
+    if not a.run_refactor:
+        raise SystemExit("only the refactored path (--run_refactor, with or without --run_cpp) is implemented here")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -124,7 +124,8 @@ def main():
         if inject_for is not None:
             inj = np.stack([inject_for(int(i))[0] for i in idx] + [np.zeros((2, 50, hp, wp), np.float16)] * (B - len(idx)))
             maps = torch.addcmul(torch.from_numpy(inj).to(dev), maps, scale)
-        rec = post.process_async(maps, H, True)          # min_img_size = img_h (evaluate.py:110)
+        # --run_cpp: pafprocess rules (evaluate.py:105-129); without it: find_connections + find_humans (:88-89, :130-156)
+        rec = post.process_async(maps, H, True) if a.run_cpp else post.process_py_async(maps, H, True)
         local_recs[b0 * RECORD_BYTES:(b0 + B) * RECORD_BYTES].copy_(rec)
     torch.cuda.synchronize()
     dt_local = time.perf_counter() - t0
