@@ -406,6 +406,49 @@ float pp_get_part_score(const pp_ctx *ctx, int cid) {
 }
 uint32_t pp_get_status(const pp_ctx *ctx) { return (ctx && ctx->have_result) ? ctx->h_record.status : 0u; }
 
+// ------------------------------------------------------------------------------------------------ original path (A10)
+int pp_original_accumulate(pp_ctx *ctx, int batch, const void *net_out_dev, int dtype, int h, int w, int flip, int pad_down,
+                           int pad_right, int img_h, int img_w, int n_scales, float *scratch_planar, float *scratch_up,
+                           double *heat_acc, double *paf_acc, void *stream) {
+    if (!ctx || !net_out_dev || !scratch_planar || !scratch_up || !heat_acc || !paf_acc || batch <= 0 || h <= 0 || w <= 0 ||
+        img_h <= 0 || img_w <= 0 || n_scales <= 0 || pad_down < 0 || pad_right < 0 || pad_down >= 4 * h || pad_right >= 4 * w ||
+        (dtype != PP_F16 && dtype != PP_F32))
+        return PP_ERR_BAD_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int uh = 4 * h, uw = 4 * w, ch = uh - pad_down, cw = uw - pad_right;
+    PP_HIP(ctx, pp::launch_flip_average_planar(net_out_dev, dtype, batch, h, w, flip, scratch_planar, st));
+    // x4 up-sample of every (image, channel) plane (utils/parse_skeletons.py:252-263)
+    PP_HIP(ctx, pp::launch_resize_cubic(scratch_planar, (long)h * w, w, h, w, scratch_up, 0, batch * PP_NUM_CH, uh, uw, 0.25, 0.25,
+                                        1.0f, st));
+    // crop the padding (:272-273), resize to the image size (:276-277), accumulate value / n_scales in float64 (:280-281)
+    const double sx = 1.0 / ((double)img_w / (double)cw), sy = 1.0 / ((double)img_h / (double)ch);
+    for (int b = 0; b < batch; b++) {
+        const float *up_b = scratch_up + (size_t)b * PP_NUM_CH * uh * uw;
+        PP_HIP(ctx, pp::launch_resize_cubic(up_b, (long)uh * uw, uw, ch, cw, paf_acc + (size_t)b * PP_NUM_LIMB * img_h * img_w, 1,
+                                            PP_NUM_LIMB, img_h, img_w, sx, sy, (float)n_scales, st));
+        PP_HIP(ctx, pp::launch_resize_cubic(up_b + (size_t)PP_NUM_LIMB * uh * uw, (long)uh * uw, uw, ch, cw,
+                                            heat_acc + (size_t)b * PP_NUM_HEAT * img_h * img_w, 1, PP_NUM_HEAT, img_h, img_w, sx,
+                                            sy, (float)n_scales, st));
+    }
+    return PP_OK;
+}
+
+int pp_original_finish(pp_ctx *ctx, int batch, int img_h, int img_w, float thre1, const double *heat_acc, const double *paf_acc,
+                       unsigned char *mask_scratch, void *peaks64_scratch, pp_record *records_dev, void *stream) {
+    if (!ctx || !heat_acc || !paf_acc || !mask_scratch || !peaks64_scratch || batch <= 0 || batch > ctx->max_batch ||
+        img_h <= 0 || img_w <= 0)
+        return PP_ERR_BAD_ARG;
+    if (pp::lds_bytes_assemble_py(ctx->maxp) > pp::kMaxDynLds) return PP_ERR_TOO_LARGE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    pp_record *rec = records_dev ? records_dev : ctx->d_records;
+    PP_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(unsigned) * (size_t)batch, st));
+    PP_HIP(ctx, pp::launch_fullres(batch, img_h, img_w, thre1, ctx->maxp, ctx->cap, img_h, heat_acc, paf_acc, mask_scratch,
+                                   peaks64_scratch, ctx->d_counts, ctx->d_conns_py, ctx->d_conn_counts, ctx->d_status, rec, st));
+    ctx->last_stream = st;
+    ctx->last_batch = batch;
+    return PP_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ Python twins, host form
 namespace {
 // all_peaks[k] in input order (what find_connections indexes with i / j); rows keep their own id (column 3)

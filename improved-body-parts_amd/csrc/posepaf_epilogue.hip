@@ -274,3 +274,75 @@ extern "C" int pp_flip_average(const void *net_out_dev, int dtype, int batch, in
                            flip, heat_hwc_dev, paf_hwc_dev);
     return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
 }
+
+// ------------------------------------------------------------------------------------------------ A0, scale != 1
+// cv2.resize(image, fx=fy=scale, INTER_CUBIC) on the uint8 image (utils/parse_skeletons.py:204): OpenCV's fixed-point
+// bicubic restated (see oracle/posepaf_oracle.c, orc_resize_cubic_u8; parity unpinned).  One thread per output pixel.
+namespace {
+__device__ __forceinline__ void cubic_coeffs_i(float x, int c[4]) {
+    const float A = -0.75f;
+    const float xp = __fadd_rn(x, 1.0f), y = __fadd_rn(1.0f, -x);
+    const float c0 = __fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(A, xp), 3.75f), xp), -6.0f), xp), 3.0f);
+    const float c1 = __fadd_rn(__fmul_rn(__fmul_rn(__fadd_rn(__fmul_rn(1.25f, x), -2.25f), x), x), 1.0f);
+    const float c2 = __fadd_rn(__fmul_rn(__fmul_rn(__fadd_rn(__fmul_rn(1.25f, y), -2.25f), y), y), 1.0f);
+    const float c3 = __fadd_rn(__fadd_rn(__fadd_rn(1.0f, -c0), -c1), -c2);
+    c[0] = __float2int_rn(__fmul_rn(c0, 2048.0f));
+    c[1] = __float2int_rn(__fmul_rn(c1, 2048.0f));
+    c[2] = __float2int_rn(__fmul_rn(c2, 2048.0f));
+    c[3] = __float2int_rn(__fmul_rn(c3, 2048.0f));
+}
+__device__ __forceinline__ int clampi_e(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__global__ __launch_bounds__(256) void k_resize_u8(const unsigned char *__restrict__ src, unsigned char *__restrict__ dst, int B,
+                                                   int sh, int sw, int dh, int dw, double scale_x, double scale_y) {
+    const long total = (long)B * dh * dw;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int dx = (int)(i % dw);
+        long t = i / dw;
+        const int dy = (int)(t % dh);
+        const long b = t / dh;
+        float fx = (float)(((double)dx + 0.5) * scale_x - 0.5);
+        const int sx = (int)floorf(fx);
+        fx = __fadd_rn(fx, -(float)sx);
+        float fy = (float)(((double)dy + 0.5) * scale_y - 0.5);
+        const int sy = (int)floorf(fy);
+        fy = __fadd_rn(fy, -(float)sy);
+        int ia[4], ib[4];
+        cubic_coeffs_i(fx, ia);
+        cubic_coeffs_i(fy, ib);
+        int acc[3] = {0, 0, 0};
+#pragma unroll
+        for (int ky = 0; ky < 4; ky++) {
+            const unsigned char *row = src + ((b * sh + clampi_e(sy - 1 + ky, 0, sh - 1)) * (long)sw) * 3;
+            int hs[3] = {0, 0, 0};
+#pragma unroll
+            for (int kx = 0; kx < 4; kx++) {
+                const unsigned char *p = row + (long)clampi_e(sx - 1 + kx, 0, sw - 1) * 3;
+                hs[0] += (int)p[0] * ia[kx];
+                hs[1] += (int)p[1] * ia[kx];
+                hs[2] += (int)p[2] * ia[kx];
+            }
+            acc[0] += hs[0] * ib[ky];
+            acc[1] += hs[1] * ib[ky];
+            acc[2] += hs[2] * ib[ky];
+        }
+        unsigned char *o = dst + i * 3;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int v = (acc[c] + (1 << 21)) >> 22;
+            o[c] = (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+    }
+}
+}  // namespace
+
+extern "C" int pp_resize_u8_cubic(const void *src, void *dst, int batch, int sh, int sw, int dh, int dw, double scale_x,
+                                  double scale_y, void *stream) {
+    if (!src || !dst || batch <= 0 || sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0) return PP_ERR_BAD_ARG;
+    const long total = (long)batch * dh * dw;
+    hipLaunchKernelGGL(k_resize_u8, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const unsigned char *>(src), static_cast<unsigned char *>(dst), batch, sh, sw, dh, dw, scale_x,
+                       scale_y);
+    return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
+}

@@ -44,5 +44,13 @@ hipError_t launch_limb_connect_py_hwc(const float *paf, int H, int W, int C, int
                                       const float4 *peaks, const int *counts, void *conns, int *conn_counts, unsigned *status,
                                       hipStream_t stream);
 
+hipError_t launch_resize_cubic(const float *src, long src_plane, int src_ld, int ch, int cw, void *dst, int acc, int C, int dh,
+                               int dw, double scale_x, double scale_y, float n_div, hipStream_t stream);
+hipError_t launch_flip_average_planar(const void *net, int dtype, int batch, int h, int w, int flip, float *out,
+                                      hipStream_t stream);
+hipError_t launch_fullres(int batch, int H, int W, float thre1, int maxp, int cap, int img_height, const double *heat_acc,
+                          const double *paf_acc, unsigned char *mask_scratch, void *peaks64, int *counts, void *conns,
+                          int *conn_counts, unsigned *status, pp_record *records, hipStream_t stream);
+
 }  // namespace pp
 #endif

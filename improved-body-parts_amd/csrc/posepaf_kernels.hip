@@ -1296,17 +1296,17 @@ __global__ __launch_bounds__(64) void k_assemble(int maxp, int explicit_ids, con
 // Restated with NumPy-2 scalar promotion (see oracle/posepaf_oracle.c, orc_py_find_humans).
 
 struct LimbLdsPy {
-    float *ax, *ay, *as, *bx, *by, *bs;  // [maxp] peak x, y (floats, not truncated), score
+    double *ax, *ay, *as, *bx, *by, *bs; // [maxp] peak x, y (not truncated), score -- float64 like the Python lists
     int *minA, *minB, *usedA, *usedB;    // [maxp]
     double *key, *c_score, *c_len;       // [cap] overall, connect_score, limb_len
     int *rank, *order, *state;           // [cap]
     unsigned *c_idx;                     // [cap]
 };
-__host__ __device__ inline size_t limb_lds_bytes_py(int maxp, int cap) { return 40 * (size_t)maxp + 8 + 40 * (size_t)cap; }
+__host__ __device__ inline size_t limb_lds_bytes_py(int maxp, int cap) { return 64 * (size_t)maxp + 8 + 40 * (size_t)cap; }
 
 __device__ inline LimbLdsPy carve_limb_lds_py(unsigned char *p, int maxp, int cap) {
     LimbLdsPy L;
-    float *f = reinterpret_cast<float *>(p);
+    double *f = reinterpret_cast<double *>(p);
     L.ax = f; f += maxp;
     L.ay = f; f += maxp;
     L.as = f; f += maxp;
@@ -1331,11 +1331,17 @@ __device__ inline LimbLdsPy carve_limb_lds_py(unsigned char *p, int maxp, int ca
     return L;
 }
 
-// one (src, dst) pair, utils/parse_skeletons.py:344-388
+// one (src, dst) pair, utils/parse_skeletons.py:344-388.  VT = dtype of the limb map the reference indexes: float32 on the
+// refactored path (cv2.resize output), float64 on the original path (predict's accumulators).
+__device__ __forceinline__ float vadd(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ double vadd(double a, double b) { return __dadd_rn(a, b); }
+__device__ __forceinline__ bool above_thre2(float v) { return v > 0.1f; }   // float32 array > python float 0.1
+__device__ __forceinline__ bool above_thre2(double v) { return v > 0.1; }
+
 template <typename Sampler>
-__device__ bool score_pair_py(const Sampler &smp, float axf, float ayf, float asf, float bxf, float byf, float bsf,
+__device__ bool score_pair_py(const Sampler &smp, double ax, double ay, double as_, double bx, double by, double bs_,
                               int img_height, double *score_out, double *overall_out, double *len_out) {
-    const double ax = (double)axf, ay = (double)ayf, bx = (double)bxf, by = (double)byf;
+    typedef decltype(smp.at(0, 0)) VT;
     const double dx = bx - ax, dy = by - ay;
     const double limb_len = sqrt(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));  // :352
     if (limb_len == 0.0) return false;                                                // :356
@@ -1343,11 +1349,11 @@ __device__ bool score_pair_py(const Sampler &smp, float axf, float ayf, float as
     const int mid_num = rn < 20 ? (int)rn : 20;                                       // :353
     const double div = (double)(mid_num - 1);
     const double stepx = mid_num > 1 ? dx / div : 0.0, stepy = mid_num > 1 ? dy / div : 0.0;
-    float resp[20];
+    VT resp[20];
     int cnt = 0;
 #pragma unroll
     for (int t = 0; t < 20; t++) {
-        float v = 0.f;
+        VT v = 0;
         if (t < mid_num) {
             // np.linspace: arange(num) * step + start, last element overwritten with stop (:361-362); step == 0 -> start
             double lx = __dadd_rn(__dmul_rn((double)t, stepx), ax), ly = __dadd_rn(__dmul_rn((double)t, stepy), ay);
@@ -1356,43 +1362,42 @@ __device__ bool score_pair_py(const Sampler &smp, float axf, float ayf, float as
                 ly = by;
             }
             v = smp.at((int)__double2ll_rn(lx), (int)__double2ll_rn(ly));  // np.round: half to even
-            if (v > 0.1f) cnt++;                                            // thre2 (:375)
+            if (above_thre2(v)) cnt++;                                      // thre2 (:375)
         }
         resp[t] = v;
     }
-    // limb_response.mean(): NumPy's float32 pairwise sum (8 running sums once n >= 8), then / n in float32
-    float sum;
+    // limb_response.mean(): NumPy's pairwise sum in the array's dtype (8 running sums once n >= 8), then / n
+    VT sum;
     if (mid_num < 8) {
-        sum = 0.f;
+        sum = 0;
 #pragma unroll
         for (int t = 0; t < 7; t++)
-            if (t < mid_num) sum = __fadd_rn(sum, resp[t]);
+            if (t < mid_num) sum = vadd(sum, resp[t]);
     } else {
-        float r[8];
+        VT r[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) r[k] = resp[k];
         const int full = mid_num - (mid_num & 7);
 #pragma unroll
         for (int t = 8; t < 16; t++)
-            if (t < full) r[t & 7] = __fadd_rn(r[t & 7], resp[t]);
-        sum = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
-                        __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
+            if (t < full) r[t & 7] = vadd(r[t & 7], resp[t]);
+        sum = vadd(vadd(vadd(r[0], r[1]), vadd(r[2], r[3])), vadd(vadd(r[4], r[5]), vadd(r[6], r[7])));
 #pragma unroll
         for (int t = 8; t < 20; t++)
-            if (t >= full && t < mid_num) sum = __fadd_rn(sum, resp[t]);
+            if (t >= full && t < mid_num) sum = vadd(sum, resp[t]);
     }
-    const float mean32 = sum / (float)mid_num;
+    const VT mean = sum / (VT)mid_num;
     const double prior = 0.5 * (double)img_height / limb_len - 1.0;  // :366
     double connect_score, half_cs;
-    if (0.0 < prior) {  // python min(prior, 0) -> int 0: float32 + 0 stays float32
-        connect_score = (double)mean32;
-        half_cs = (double)__fmul_rn(0.5f, mean32);
-    } else {            // float32 + float64 -> float64
-        connect_score = __dadd_rn((double)mean32, prior);
+    if (sizeof(VT) == 4 && 0.0 < prior) {  // python min(prior, 0) -> int 0: float32 + 0 stays float32
+        connect_score = (double)mean;
+        half_cs = (double)__fmul_rn(0.5f, (float)mean);
+    } else {                                // float64 arithmetic (float32 + float64, or a float64 map)
+        connect_score = 0.0 < prior ? (double)mean : __dadd_rn((double)mean, prior);
         half_cs = __dmul_rn(0.5, connect_score);
     }
     if (!((double)cnt > __dmul_rn((double)mid_num, 0.8) && connect_score > 0.0)) return false;  // :375-378
-    *overall_out = __dadd_rn(__dadd_rn(half_cs, __dmul_rn(0.25, (double)asf)), __dmul_rn(0.25, (double)bsf));  // :381
+    *overall_out = __dadd_rn(__dadd_rn(half_cs, __dmul_rn(0.25, as_)), __dmul_rn(0.25, bs_));  // :381
     *score_out = connect_score;
     *len_out = limb_len;
     return true;
@@ -1630,7 +1635,10 @@ __host__ __device__ inline size_t assemble_py_lds_bytes(int maxp) {
     return (size_t)kMaxSkelPy * kSkelStride * 16 + (size_t)PP_NUM_PART * maxp * 16 + (size_t)PP_NUM_LIMB * maxp * 32;
 }
 
-__global__ __launch_bounds__(64) void k_assemble_py(int maxp, int explicit_ids, const float4 *__restrict__ peaks,
+// PK = float4: refactored path (integer-valued coordinates, int x / y in the record); PK = double4: original path
+// (fractional coordinates: the record's x / y fields then hold FLOAT bit patterns and PP_ST_FLOAT_COORDS is set).
+template <typename PK>
+__global__ __launch_bounds__(64) void k_assemble_py(int maxp, int explicit_ids, const PK *__restrict__ peaks,
                                                     const int *__restrict__ counts, const double4 *__restrict__ conns,
                                                     const int *__restrict__ conn_counts, unsigned *__restrict__ status,
                                                     pp_record *__restrict__ records, double *__restrict__ persons_out,
@@ -1641,16 +1649,17 @@ __global__ __launch_bounds__(64) void k_assemble_py(int maxp, int explicit_ids, 
     double *pid = reinterpret_cast<double *>(lds_raw);                 // [kMaxSkelPy][21]
     double *psc = pid + kMaxSkelPy * kSkelStride;
     double4 *s_conn = reinterpret_cast<double4 *>(psc + kMaxSkelPy * kSkelStride);  // {src_id, dst_id, score, len}
-    int *line_x = reinterpret_cast<int *>(s_conn + PP_NUM_LIMB * maxp);
-    int *line_y = line_x + ntab;
-    float *line_s = reinterpret_cast<float *>(line_y + ntab);
+    float *line_x = reinterpret_cast<float *>(s_conn + PP_NUM_LIMB * maxp);
+    float *line_y = line_x + ntab;
+    float *line_s = line_y + ntab;
+    constexpr bool kFloatCoords = sizeof(PK) == sizeof(double4);
     __shared__ int s_off[PP_NUM_PART + 1];
     __shared__ int s_cnt[PP_NUM_PART];
     __shared__ int s_coff[PP_NUM_LIMB + 1];
     __shared__ int s_merge;
 
     const int *cnt_g = counts + img * PP_NUM_PART;
-    const float4 *pk_g = peaks + (size_t)img * PP_NUM_PART * maxp;
+    const PK *pk_g = peaks + (size_t)img * PP_NUM_PART * maxp;
     if (lane == 0) {
         int run = 0;
         for (int k = 0; k < PP_NUM_PART; k++) {
@@ -1674,10 +1683,10 @@ __global__ __launch_bounds__(64) void k_assemble_py(int maxp, int explicit_ids, 
     for (int part = 0; part < PP_NUM_PART; part++) {  // joint_candidates: rows flattened in part order (:423)
         const int c = s_cnt[part], o = s_off[part];
         for (int r = lane; r < c; r += 64) {
-            const float4 p = pk_g[(size_t)part * maxp + r];
-            line_x[o + r] = (int)p.x;
-            line_y[o + r] = (int)p.y;
-            line_s[o + r] = p.z;
+            const PK p = pk_g[(size_t)part * maxp + r];
+            line_x[o + r] = (float)p.x;
+            line_y[o + r] = (float)p.y;
+            line_s[o + r] = (float)p.z;
         }
     }
     for (int limb = 0; limb < PP_NUM_LIMB; limb++) {
@@ -1824,8 +1833,9 @@ __global__ __launch_bounds__(64) void k_assemble_py(int maxp, int explicit_ids, 
                     const int id = (int)pid[s * kSkelStride + kp];
                     hm->peak_id[kp] = id;
                     const bool ok = id >= 0 && id < n_peaks;
-                    hm->x[kp] = ok ? line_x[id] : 0;
-                    hm->y[kp] = ok ? line_y[id] : 0;
+                    const float fx = ok ? line_x[id] : 0.0f, fy = ok ? line_y[id] : 0.0f;
+                    hm->x[kp] = kFloatCoords ? __float_as_int(fx) : (int)fx;
+                    hm->y[kp] = kFloatCoords ? __float_as_int(fy) : (int)fy;
                     hm->part_score[kp] = ok ? line_s[id] : 0.0f;
                 }
                 hm->score = (float)(pid[s * kSkelStride + 18] / pid[s * kSkelStride + 19]);
@@ -1850,8 +1860,250 @@ __global__ __launch_bounds__(64) void k_assemble_py(int maxp, int explicit_ids, 
         rec->n_humans = n_out;
         rec->n_peaks = n_peaks;
         rec->n_connections = s_coff[PP_NUM_LIMB];
-        rec->status = status[img] | st;
+        rec->status = status[img] | st | (kFloatCoords ? PP_ST_FLOAT_COORDS : 0u);
     }
+}
+
+// ================================================================================================ A10: original path
+// predict (utils/parse_skeletons.py:180-283): maps of every scale are up-sampled x4, cropped, resized to the image size
+// and averaged in float64; find_peaks (:286-321): 3x3 / >= thre1 NMS + refine_centroid at IMAGE resolution; then the
+// Python twins on the float64 limb maps.  Maps of that size (512 x 512 x 50 x 8 B = 105 MB per image) live in HBM.
+
+// OpenCV interpolateCubic (A = -0.75) in float with separately rounded operations (oracle: orc_cubic_coeffs)
+__device__ __forceinline__ void cubic_coeffs(float x, float c[4]) {
+    const float A = -0.75f;
+    const float xp = __fadd_rn(x, 1.0f);
+    c[0] = __fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(A, xp), 3.75f), xp), -6.0f), xp), 3.0f);
+    c[1] = __fadd_rn(__fmul_rn(__fmul_rn(__fadd_rn(__fmul_rn(1.25f, x), -2.25f), x), x), 1.0f);
+    const float y = __fadd_rn(1.0f, -x);
+    c[2] = __fadd_rn(__fmul_rn(__fmul_rn(__fadd_rn(__fmul_rn(1.25f, y), -2.25f), y), y), 1.0f);
+    c[3] = __fadd_rn(__fadd_rn(__fadd_rn(1.0f, -c[0]), -c[1]), -c[2]);
+}
+
+// Generic cv2.resize(INTER_CUBIC) of planar float maps: src (C, src_h_alloc, src_ld) of which rows [0, ch) x cols [0, cw)
+// are the image (crop), dst (C, dh, dw).  ACC: dst is float64 and receives dst += (double)(value / n) (:280-281).
+template <bool ACC>
+__global__ __launch_bounds__(256) void k_resize_cubic(const float *__restrict__ src, long src_plane, int src_ld, int ch, int cw,
+                                                      void *__restrict__ dst_, int C, int dh, int dw, double scale_x,
+                                                      double scale_y, float n_div, int identity) {
+    const long total = (long)C * dh * dw;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int dx = (int)(i % dw);
+        long t = i / dw;
+        const int dy = (int)(t % dh);
+        const int c = (int)(t / dh);
+        const float *S = src + (long)c * src_plane;
+        float v;
+        if (identity) {  // cv2.resize copies when the size does not change
+            v = S[(long)dy * src_ld + dx];
+        } else {
+            float fx = (float)(((double)dx + 0.5) * scale_x - 0.5);
+            const int sx = (int)floorf(fx);
+            fx = __fadd_rn(fx, -(float)sx);
+            float fy = (float)(((double)dy + 0.5) * scale_y - 0.5);
+            const int sy = (int)floorf(fy);
+            fy = __fadd_rn(fy, -(float)sy);
+            float a[4], b[4];
+            cubic_coeffs(fx, a);
+            cubic_coeffs(fy, b);
+            const int x0 = clampi(sx - 1, 0, cw - 1), x1 = clampi(sx, 0, cw - 1), x2 = clampi(sx + 1, 0, cw - 1),
+                      x3 = clampi(sx + 2, 0, cw - 1);
+            float hrow[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float *row = S + (long)clampi(sy - 1 + k, 0, ch - 1) * src_ld;
+                float h = __fmul_rn(row[x0], a[0]);
+                h = __fadd_rn(h, __fmul_rn(row[x1], a[1]));
+                h = __fadd_rn(h, __fmul_rn(row[x2], a[2]));
+                h = __fadd_rn(h, __fmul_rn(row[x3], a[3]));
+                hrow[k] = h;
+            }
+            v = __fmul_rn(hrow[0], b[0]);
+            v = __fadd_rn(v, __fmul_rn(hrow[1], b[1]));
+            v = __fadd_rn(v, __fmul_rn(hrow[2], b[2]));
+            v = __fadd_rn(v, __fmul_rn(hrow[3], b[3]));
+        }
+        if (ACC) {
+            double *D = static_cast<double *>(dst_);
+            D[i] = __dadd_rn(D[i], (double)(v / n_div));
+        } else {
+            static_cast<float *>(dst_)[i] = v;
+        }
+    }
+}
+
+// flip-average to PLANAR float32 (B, 50, h, w) (the HWC form of posepaf_epilogue.hip is for host callers)
+template <typename T>
+__global__ __launch_bounds__(256) void k_flip_average_planar(const T *__restrict__ net, int batch, int h, int w, int flip,
+                                                             float *__restrict__ out) {
+    const long plane = (long)h * w;
+    const long total = (long)batch * PP_NUM_CH * plane;
+    const long stride = (long)gridDim.x * blockDim.x;
+    const int ns = flip ? 2 : 1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int x = (int)(i % w);
+        long t = i / w;
+        const int y = (int)(t % h);
+        t /= h;
+        const int c = (int)(t % PP_NUM_CH);
+        const long b = t / PP_NUM_CH;
+        const int cf = c < PP_NUM_LIMB ? d_flip_paf_ord[c] : PP_NUM_LIMB + d_flip_heat_ord[c - PP_NUM_LIMB];
+        const long i0 = ((b * ns) * PP_NUM_CH + c) * plane + (long)y * w + x;
+        const long i1 = ((b * ns + 1) * PP_NUM_CH + cf) * plane + (long)y * w + (w - 1 - x);
+        float v;
+        if (sizeof(T) == 2) {
+            const __half *p = reinterpret_cast<const __half *>(net);
+            v = flip ? __half2float(__hmul(__hadd(p[i0], p[i1]), __float2half(0.5f))) : __half2float(p[i0]);
+        } else {
+            const float *p = reinterpret_cast<const float *>(net);
+            v = flip ? __fadd_rn(p[i0], p[i1]) / 2.0f : p[i0];
+        }
+        out[i] = v;
+    }
+}
+
+// find_peaks at image resolution: one workgroup per (part, image).  The float64 accumulator is cast to float32 on read
+// (:290); 3x3 / >= thre NMS (reflect padding == ignore out-of-map neighbours); np.nonzero order via per-thread contiguous
+// pixel ranges + block scan; refine_centroid per peak.  peaks: double4 (x, y, score, id-unused).
+__global__ __launch_bounds__(kThreads) void k_fullres_peaks(const double *__restrict__ heat_acc, int H, int W, float thre,
+                                                            int maxp, unsigned char *__restrict__ mask_scratch,
+                                                            double4 *__restrict__ peaks, int *__restrict__ counts,
+                                                            unsigned *__restrict__ status) {
+    __shared__ int s_wsum[kWaves];
+    __shared__ int s_pk[PP_MAX_PEAKS_PER_PART_LIMIT];
+    const int part = blockIdx.x, img = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long npix = (long)H * W;
+    const double *M = heat_acc + ((long)img * PP_NUM_HEAT + part) * npix;
+    unsigned char *mask = mask_scratch + ((long)img * PP_NUM_PART + part) * npix;
+    auto val = [&](long i) -> float { return (float)M[i]; };
+    for (long i = threadIdx.x; i < npix; i += kThreads) {
+        const float v = val(i);
+        unsigned char pk = 0;
+        if (v >= thre) {
+            const int y = (int)(i / W), x = (int)(i - (long)y * W);
+            pk = 1;
+            for (int dy = -1; dy <= 1 && pk; dy++) {
+                const int yy = y + dy;
+                if (yy < 0 || yy >= H) continue;
+                for (int dx = -1; dx <= 1; dx++) {
+                    const int xx = x + dx;
+                    if (xx < 0 || xx >= W) continue;
+                    if (val((long)yy * W + xx) > v) {
+                        pk = 0;
+                        break;
+                    }
+                }
+            }
+        }
+        mask[i] = pk;
+    }
+    __syncthreads();  // same workgroup: its global writes are visible to it after the barrier
+    const long ppt = (npix + kThreads - 1) / kThreads;
+    const long b0 = (long)threadIdx.x * ppt;
+    int cnt = 0;
+    for (long q = b0; q < b0 + ppt && q < npix; q++) cnt += mask[q];
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int n = __shfl_up(incl, d);
+        if (lane >= d) incl += n;
+    }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    int rank = incl - cnt;
+    for (int q = 0; q < wave; q++) rank += s_wsum[q];
+    int total = 0;
+    for (int q = 0; q < kWaves; q++) total += s_wsum[q];
+    for (long q = b0; q < b0 + ppt && q < npix && rank < maxp; q++)
+        if (mask[q]) s_pk[rank++] = (int)q;
+    __syncthreads();
+    const int kept = total < maxp ? total : maxp;
+    double4 *out = peaks + ((long)img * PP_NUM_PART + part) * maxp;
+    for (int p = wave; p < kept; p += kWaves) {  // refine_centroid, radius 2 (utils/util.py:188-213)
+        const int i = s_pk[p];
+        const int py = i / W, px = i - py * W;
+        double ox, oy, sc;
+        if (py - 2 < 0 || py + 3 > H || px - 2 < 0 || px + 3 > W) {
+            ox = (double)px;
+            oy = (double)py;
+            sc = (double)val(i);
+        } else {
+            double sx = 0.0, sy = 0.0, sv = 0.0;
+            if (lane < 25) {
+                const int r = lane / 5, c = lane - r * 5;
+                const double v = (double)val((long)(py - 2 + r) * W + (px - 2 + c));
+                sx = v * (double)(r - 2);  // x_grid varies along rows (np.mgrid): restated as written
+                sy = v * (double)(c - 2);
+                sv = v;
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                sx += __shfl_xor(sx, d);
+                sy += __shfl_xor(sy, d);
+                sv += __shfl_xor(sv, d);
+            }
+            ox = (double)px + sx / sv;
+            oy = (double)py + sy / sv;
+            sc = sv / 25.0;
+        }
+        if (lane == 0) out[p] = make_double4(ox, oy, (double)(float)sc, 0.0);  // box.mean() is a float32 scalar
+    }
+    if (threadIdx.x == 0) {
+        counts[img * PP_NUM_PART + part] = total;
+        if (total > maxp) atomicOr(&status[img], PP_ST_PEAK_OVERFLOW);
+    }
+}
+
+struct GlobalPlanarF64Sampler {  // predict's paf_avg, planar (30, H, W) float64
+    const double *paf;
+    int H, W;
+    __device__ __forceinline__ double at(int X, int Y) const {
+        X = clampi(X, 0, W - 1);
+        Y = clampi(Y, 0, H - 1);
+        return paf[(long)Y * W + X];
+    }
+};
+
+__global__ __launch_bounds__(kThreads) void k_limb_connect_py_fullres(const double *__restrict__ paf_acc, int H, int W, int maxp,
+                                                                      int cap, int img_height,
+                                                                      const double4 *__restrict__ peaks,
+                                                                      const int *__restrict__ counts, double4 *__restrict__ conns,
+                                                                      int *__restrict__ conn_counts, unsigned *__restrict__ status) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int limb = blockIdx.x, img = blockIdx.y;
+    const int pa = d_limb_pairs[limb][0], pb = d_limb_pairs[limb][1];
+    int nA = counts[img * PP_NUM_PART + pa], nB = counts[img * PP_NUM_PART + pb];
+    nA = nA < maxp ? nA : maxp;
+    nB = nB < maxp ? nB : maxp;
+    int *cc = conn_counts + img * PP_NUM_LIMB + limb;
+    if (nA == 0 || nB == 0) {
+        if (threadIdx.x == 0) *cc = 0;
+        return;
+    }
+    LimbLdsPy L = carve_limb_lds_py(lds_raw, maxp, cap);
+    const double4 *pka = peaks + ((long)img * PP_NUM_PART + pa) * maxp;
+    const double4 *pkb = peaks + ((long)img * PP_NUM_PART + pb) * maxp;
+    for (int i = threadIdx.x; i < nA; i += kThreads) {
+        const double4 p = pka[i];
+        L.ax[i] = p.x;
+        L.ay[i] = p.y;
+        L.as[i] = p.z;
+    }
+    for (int i = threadIdx.x; i < nB; i += kThreads) {
+        const double4 p = pkb[i];
+        L.bx[i] = p.x;
+        L.by[i] = p.y;
+        L.bs[i] = p.z;
+    }
+    for (int i = threadIdx.x; i < maxp; i += kThreads) {
+        L.usedA[i] = 0;
+        L.usedB[i] = 0;
+    }
+    __syncthreads();
+    GlobalPlanarF64Sampler smp{paf_acc + ((long)img * PP_NUM_LIMB + limb) * (long)H * W, H, W};
+    connect_limb_py(smp, L, nA, nB, cap, maxp, img_height, conns + ((long)img * PP_NUM_LIMB + limb) * maxp, cc, status + img);
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
@@ -1883,7 +2135,9 @@ hipError_t init_kernel_attributes() {
                          reinterpret_cast<const void *>(&k_limb_connect_py<__half>),
                          reinterpret_cast<const void *>(&k_limb_connect_py<float>),
                          reinterpret_cast<const void *>(&k_limb_connect_py_hwc),
-                         reinterpret_cast<const void *>(&k_assemble_py)};
+                         reinterpret_cast<const void *>(&k_assemble_py<float4>),
+                         reinterpret_cast<const void *>(&k_assemble_py<double4>),
+                         reinterpret_cast<const void *>(&k_limb_connect_py_fullres)};
     for (const void *f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
         if (e != hipSuccess) return e;
@@ -1967,8 +2221,53 @@ hipError_t launch_limb_connect_py(const void *net, int dtype, int batch, int n_s
 hipError_t launch_assemble_py(int batch, int maxp, int explicit_ids, const float4 *peaks, const int *counts, const void *conns,
                               const int *conn_counts, unsigned *status, pp_record *records, double *persons_out,
                               int *n_persons_out, hipStream_t stream) {
-    hipLaunchKernelGGL(k_assemble_py, dim3(batch), dim3(64), lds_bytes_assemble_py(maxp), stream, maxp, explicit_ids, peaks,
-                       counts, static_cast<const double4 *>(conns), conn_counts, status, records, persons_out, n_persons_out);
+    hipLaunchKernelGGL(k_assemble_py<float4>, dim3(batch), dim3(64), lds_bytes_assemble_py(maxp), stream, maxp, explicit_ids,
+                       peaks, counts, static_cast<const double4 *>(conns), conn_counts, status, records, persons_out,
+                       n_persons_out);
+    return hipGetLastError();
+}
+
+// ---- original path
+hipError_t launch_resize_cubic(const float *src, long src_plane, int src_ld, int ch, int cw, void *dst, int acc, int C, int dh,
+                               int dw, double scale_x, double scale_y, float n_div, hipStream_t stream) {
+    const long total = (long)C * dh * dw;
+    long blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    const int identity = (ch == dh && cw == dw) ? 1 : 0;
+    if (acc)
+        hipLaunchKernelGGL(k_resize_cubic<true>, dim3(blocks), dim3(256), 0, stream, src, src_plane, src_ld, ch, cw, dst, C, dh, dw,
+                           scale_x, scale_y, n_div, identity);
+    else
+        hipLaunchKernelGGL(k_resize_cubic<false>, dim3(blocks), dim3(256), 0, stream, src, src_plane, src_ld, ch, cw, dst, C, dh,
+                           dw, scale_x, scale_y, n_div, identity);
+    return hipGetLastError();
+}
+
+hipError_t launch_flip_average_planar(const void *net, int dtype, int batch, int h, int w, int flip, float *out,
+                                      hipStream_t stream) {
+    const long total = (long)batch * PP_NUM_CH * h * w;
+    long blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    if (dtype == PP_F16)
+        hipLaunchKernelGGL(k_flip_average_planar<__half>, dim3(blocks), dim3(256), 0, stream, static_cast<const __half *>(net),
+                           batch, h, w, flip, out);
+    else
+        hipLaunchKernelGGL(k_flip_average_planar<float>, dim3(blocks), dim3(256), 0, stream, static_cast<const float *>(net),
+                           batch, h, w, flip, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_fullres(int batch, int H, int W, float thre1, int maxp, int cap, int img_height, const double *heat_acc,
+                          const double *paf_acc, unsigned char *mask_scratch, void *peaks64, int *counts, void *conns,
+                          int *conn_counts, unsigned *status, pp_record *records, hipStream_t stream) {
+    hipLaunchKernelGGL(k_fullres_peaks, dim3(PP_NUM_PART, batch), dim3(kThreads), 0, stream, heat_acc, H, W, thre1, maxp,
+                       mask_scratch, static_cast<double4 *>(peaks64), counts, status);
+    hipLaunchKernelGGL(k_limb_connect_py_fullres, dim3(PP_NUM_LIMB, batch), dim3(kThreads), limb_lds_bytes_py(maxp, cap), stream,
+                       paf_acc, H, W, maxp, cap, img_height, static_cast<const double4 *>(peaks64), counts,
+                       static_cast<double4 *>(conns), conn_counts, status);
+    hipLaunchKernelGGL(k_assemble_py<double4>, dim3(batch), dim3(64), lds_bytes_assemble_py(maxp), stream, maxp, 0,
+                       static_cast<const double4 *>(peaks64), counts, static_cast<const double4 *>(conns), conn_counts, status,
+                       records, static_cast<double *>(nullptr), static_cast<int *>(nullptr));
     return hipGetLastError();
 }
 

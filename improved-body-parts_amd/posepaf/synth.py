@@ -144,3 +144,21 @@ def make_scene(n_people: int, seed: int, h: int = 128, w: int = 128, noise: floa
     if noise > 0:
         out = out + rng.normal(0.0, noise, size=out.shape).astype(np.float32)
     return np.ascontiguousarray(out.astype(dtype)), joints
+
+
+def make_scene_at_scales(n_people: int, seed: int, sizes, noise: float = 0.02, dtype=np.float16, p_missing: float = 0.08,
+                         img: int = 512):
+    """The SAME people rendered on feature maps of several sizes (a scale search): -> (list of (2,50,h,w) outputs, joints).
+    sizes: list of (h, w, scale) with the map showing the image scaled by `scale` (top-left aligned, padding beyond)."""
+    rng = np.random.default_rng(seed)
+    joints = random_people(n_people, rng, img_h=img, img_w=img, p_missing=p_missing)
+    outs = []
+    for (h, w, scale) in sizes:
+        j = joints.copy()
+        j[:, :, :2] *= scale
+        base = render_maps(j, h, w)
+        out = np.stack([base, mirror_sample(base)]).astype(np.float32)
+        if noise > 0:
+            out = out + rng.normal(0.0, noise, size=out.shape).astype(np.float32)
+        outs.append(np.ascontiguousarray(out.astype(dtype)))
+    return outs, joints

@@ -55,6 +55,7 @@ typedef enum { PP_F32 = 0, PP_F16 = 1 } pp_dtype;
 #define PP_ST_SORT_UNDEFINED 8u  /* the reference's std::sort (non-strict comparator, pafprocess.cpp:333-335)
                                     would have read outside its array on this input: its result is undefined */
 #define PP_ST_CAND_OVERFLOW 16u  /* more accepted limb candidates for one limb than the kernel holds */
+#define PP_ST_FLOAT_COORDS 32u   /* original path: pp_human.x / .y hold float32 BIT PATTERNS (fractional coordinates) */
 
 /* One person.  Mirrors what evaluate.py:111-127 pulls through the getters:
  * peak_id[p] = get_part_peak_id(h,p) (-1 = part absent); x/y/part_score = get_part_x/y/score(peak_id);
@@ -188,6 +189,25 @@ PP_API int pp_get_part_x(const pp_ctx *ctx, int cid);
 PP_API int pp_get_part_y(const pp_ctx *ctx, int cid);
 PP_API float pp_get_part_score(const pp_ctx *ctx, int cid);
 PP_API uint32_t pp_get_status(const pp_ctx *ctx);
+
+/* ---------------------------------------------------------------- original (non-refactored) path, SURVEY 8a row A10
+ * predict (utils/parse_skeletons.py:180-283) + find_peaks (:286-321) + find_connections / find_humans at IMAGE
+ * resolution, with a real scale search (BASELINE config 5).  All buffers are DEVICE memory owned by the caller:
+ *   scratch_planar float[batch][50][h][w], scratch_up float[batch][50][4h][4w],
+ *   heat_acc double[batch][20][img_h][img_w], paf_acc double[batch][30][img_h][img_w]  (zero them before the first scale),
+ *   mask_scratch uchar[batch][18][img_h][img_w], peaks64_scratch 32 bytes x batch x 18 x max_peaks_per_part.
+ * pp_original_accumulate adds ONE scale: flip-average, x4 bicubic, crop of (pad_down, pad_right) pixels, bicubic resize to
+ * (img_h, img_w), += value / n_scales.  pp_original_finish: 3x3 / >= thre1 NMS + refine_centroid, Python-twin matching
+ * on the float64 limb maps, records with PP_ST_FLOAT_COORDS (x / y are float32 bit patterns).
+ * pp_resize_u8_cubic: cv2.resize(INTER_CUBIC) of a batch of interleaved 3-channel uint8 images (scale = src / dst). */
+PP_API int pp_original_accumulate(pp_ctx *ctx, int batch, const void *net_out_dev, int dtype, int h, int w, int flip,
+                                  int pad_down, int pad_right, int img_h, int img_w, int n_scales, float *scratch_planar,
+                                  float *scratch_up, double *heat_acc, double *paf_acc, void *stream);
+PP_API int pp_original_finish(pp_ctx *ctx, int batch, int img_h, int img_w, float thre1, const double *heat_acc,
+                              const double *paf_acc, unsigned char *mask_scratch, void *peaks64_scratch, pp_record *records_dev,
+                              void *stream);
+PP_API int pp_resize_u8_cubic(const void *src, void *dst, int batch, int sh, int sw, int dh, int dw, double scale_x,
+                              double scale_y, void *stream);
 
 /* ---------------------------------------------------------------- Python twins, host form
  * utils.parse_skeletons.find_connections / find_humans (:324-600) with host arrays, for callers of the non --run_cpp

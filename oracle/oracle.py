@@ -80,6 +80,12 @@ class Oracle:
                                           C.POINTER(C.c_double)]
         L.orc_py_find_humans.argtypes = [C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]
+        dp = C.POINTER(C.c_double)
+        L.orc_predict_accumulate.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                             C.c_int, dp, dp]
+        L.orc_find_peaks_original.argtypes = [dp, C.c_int, C.c_int, C.c_float, dp, C.c_int]
+        L.orc_py_find_humans_f64.argtypes = [dp, C.c_int, dp, C.c_int, C.c_int, C.c_int, dp, C.c_int, C.POINTER(C.c_int)]
+        L.orc_resize_cubic_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double]
         L.orc_f32_to_f16.argtypes = [C.c_float]
         L.orc_f32_to_f16.restype = C.c_uint16
         L.orc_f16_to_f32.argtypes = [C.c_uint16]
@@ -154,6 +160,46 @@ class Oracle:
         out = (C.c_double * 3)()
         self.L.orc_refine_centroid(_fp(m), m.shape[0], m.shape[1], x, y, radius, out)
         return tuple(out)
+
+    def predict_accumulate(self, net_out, pad_down, pad_right, img_h, img_w, n_scales, heat_acc, paf_acc, flip=True):
+        """one scale of predict(): accumulates into planar float64 heat_acc (20,H,W) / paf_acc (30,H,W) in place"""
+        net_out = np.ascontiguousarray(net_out)
+        is_f16 = net_out.dtype == np.float16
+        _, _, h, w = net_out.shape
+        dp = C.POINTER(C.c_double)
+        self.L.orc_predict_accumulate(net_out.ctypes.data_as(C.c_void_p), int(is_f16), h, w, int(flip), pad_down, pad_right,
+                                      img_h, img_w, n_scales, heat_acc.ctypes.data_as(dp), paf_acc.ctypes.data_as(dp))
+
+    def find_peaks_original(self, heat_acc, thre1=0.1):
+        _, H, W = heat_acc.shape
+        cap = 18 * 4096
+        rows = np.empty((cap, 5), np.float64)
+        n = self.L.orc_find_peaks_original(heat_acc.ctypes.data_as(C.POINTER(C.c_double)), H, W, thre1,
+                                           rows.ctypes.data_as(C.POINTER(C.c_double)), cap)
+        return rows[:min(n, cap)].copy()
+
+    def py_find_humans_f64(self, rows, paf_acc, img_height):
+        """original path: rows (N,5) float64 from find_peaks_original, paf_acc planar (30,H,W) float64"""
+        rows = np.ascontiguousarray(rows, np.float64).reshape(-1, 5)
+        paf_acc = np.ascontiguousarray(paf_acc, np.float64)
+        _, H, W = paf_acc.shape
+        cap = 512
+        out = np.empty((cap, 20, 2), np.float64)
+        ncn = np.zeros(NUM_LIMB, np.int32)
+        dp = C.POINTER(C.c_double)
+        n = self.L.orc_py_find_humans_f64(rows.ctypes.data_as(dp), len(rows), paf_acc.ctypes.data_as(dp), H, W, int(img_height),
+                                          out.ctypes.data_as(dp), cap, _ip(ncn))
+        return out[:n].copy(), ncn
+
+    def resize_u8(self, img, fx, fy):
+        """cv2.resize(img, (0,0), fx=fx, fy=fy, INTER_CUBIC) for uint8 HWC (restated, unpinned)"""
+        img = np.ascontiguousarray(img, np.uint8)
+        sh, sw, cn = img.shape
+        dh, dw = int(round(sh * fy)), int(round(sw * fx))
+        out = np.empty((dh, dw, cn), np.uint8)
+        self.L.orc_resize_cubic_u8(img.ctypes.data_as(C.c_void_p), sh, sw, cn, out.ctypes.data_as(C.c_void_p), dh, dw,
+                                   1.0 / fx, 1.0 / fy)
+        return out
 
     def py_find_humans(self, joint_list: np.ndarray, paf_hwc: np.ndarray, img_height: int):
         """find_connections + find_humans (the pure-Python twins): -> persons (P,20,2) float64, n_connections (30,)"""

@@ -902,9 +902,26 @@ static int pycand_cmp(const void *pa, const void *pb) { /* sorted(key=overall, r
     return a->gen < b->gen ? -1 : (a->gen > b->gen ? 1 : 0);
 }
 
-int orc_py_find_humans(const float *peaks, int n_peaks, const float *paf, int H, int W, int C, int img_height,
-                       double *persons_out, int cap, int *n_conn_out) {
-    (void)H;
+static double f64_pairwise_sum(const double *a, int n) {
+    if (n < 8) {
+        double res = 0.;
+        for (int i = 0; i < n; i++) res += a[i];
+        return res;
+    }
+    double r[8];
+    for (int k = 0; k < 8; k++) r[k] = a[k];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8)
+        for (int k = 0; k < 8; k++) r[k] += a[i + k];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res += a[i];
+    return res;
+}
+
+/* peaks: rows of 5 doubles [x, y, score, id, part].  paf32: (H, W, C) float32 (refactored path) or NULL;
+ * paf64: planar (C, H, W) float64 (original path: predict's accumulators) or NULL. */
+static int py_find_humans_core(const double *peaks, int n_peaks, const float *paf32, const double *paf64, int H, int W, int C,
+                               int img_height, double *persons_out, int cap, int *n_conn_out) {
     /* all_peaks[k]: rows of part k in input order; joint_candidates = the same rows flattened in part order */
     int *part_idx[ORC_NUM_PART], part_n[ORC_NUM_PART];
     for (int k = 0; k < ORC_NUM_PART; k++) {
@@ -920,7 +937,7 @@ int orc_py_find_humans(const float *peaks, int n_peaks, const float *paf, int H,
         int q = 0;
         for (int k = 0; k < ORC_NUM_PART; k++)
             for (int t = 0; t < part_n[k]; t++, q++)
-                for (int e = 0; e < 4; e++) cand[4 * q + e] = (double)peaks[5 * part_idx[k][t] + e];
+                for (int e = 0; e < 4; e++) cand[4 * q + e] = peaks[5 * part_idx[k][t] + e];
     }
     /* ---- find_connections */
     typedef struct {
@@ -938,43 +955,55 @@ int orc_py_find_humans(const float *peaks, int n_peaks, const float *paf, int H,
         pycand_t *cs = (pycand_t *)malloc(sizeof(pycand_t) * (size_t)(ns * nd > 0 ? ns * nd : 1));
         int nc = 0;
         for (int i = 0; i < ns; i++) {
-            const float *S = peaks + 5 * part_idx[ps][i];
+            const double *S = peaks + 5 * part_idx[ps][i];
             for (int j = 0; j < nd; j++) {
-                const float *D = peaks + 5 * part_idx[pd][j];
-                const double dx = (double)D[0] - (double)S[0], dy = (double)D[1] - (double)S[1];
+                const double *D = peaks + 5 * part_idx[pd][j];
+                const double dx = D[0] - S[0], dy = D[1] - S[1];
                 const double limb_len = sqrt(dx * dx + dy * dy);         /* :352 */
                 long rn = lrint(limb_len + 1.0);                         /* round(): half to even (default mode) */
                 int mid_num = rn < 20 ? (int)rn : 20;                    /* :353 */
                 if (limb_len == 0.0) continue;                           /* :356 */
                 float resp[20];
+                double resp64[20];
                 int cnt = 0;
                 for (int t = 0; t < mid_num; t++) {                      /* np.round(np.linspace(...)) :361-362 [!=cpp] */
                     double lx, ly;
                     if (mid_num == 1) {
-                        lx = (double)S[0];
-                        ly = (double)S[1];
+                        lx = S[0];
+                        ly = S[1];
                     } else {
                         const double stepx = dx / (double)(mid_num - 1), stepy = dy / (double)(mid_num - 1);
-                        lx = (stepx == 0.0) ? ((double)t / (double)(mid_num - 1)) * dx + (double)S[0] : (double)t * stepx + (double)S[0];
-                        ly = (stepy == 0.0) ? ((double)t / (double)(mid_num - 1)) * dy + (double)S[1] : (double)t * stepy + (double)S[1];
+                        lx = (stepx == 0.0) ? ((double)t / (double)(mid_num - 1)) * dx + S[0] : (double)t * stepx + S[0];
+                        ly = (stepy == 0.0) ? ((double)t / (double)(mid_num - 1)) * dy + S[1] : (double)t * stepy + S[1];
                         if (t == mid_num - 1) {
-                            lx = (double)D[0];
-                            ly = (double)D[1];
+                            lx = D[0];
+                            ly = D[1];
                         }
                     }
                     const long ix = lrint(lx), iy = lrint(ly);
-                    resp[t] = paf[pair + (size_t)C * ((size_t)ix + (size_t)W * (size_t)iy)];
-                    if (resp[t] > 0.1f) cnt++;                           /* thre2, :375 */
+                    if (paf32) {
+                        resp[t] = paf32[pair + (size_t)C * ((size_t)ix + (size_t)W * (size_t)iy)];
+                        if (resp[t] > 0.1f) cnt++;                       /* thre2, :375 (float32 array > 0.1) */
+                    } else {
+                        resp64[t] = paf64[((size_t)pair * H + (size_t)iy) * W + (size_t)ix];
+                        if (resp64[t] > 0.1) cnt++;
+                    }
                 }
-                const float mean32 = f32_pairwise_sum(resp, mid_num) / (float)mid_num;
                 const double prior = 0.5 * (double)img_height / limb_len - 1.0;
                 double connect_score; /* :366  min(prior, 0): python min keeps the np.float64 unless 0 < prior */
                 int score_is_f32;
-                if (0.0 < prior) {
-                    connect_score = (double)mean32; /* float32 + int 0 -> float32 */
-                    score_is_f32 = 1;
+                if (paf32) {
+                    const float mean32 = f32_pairwise_sum(resp, mid_num) / (float)mid_num;
+                    if (0.0 < prior) {
+                        connect_score = (double)mean32; /* float32 + int 0 -> float32 */
+                        score_is_f32 = 1;
+                    } else {
+                        connect_score = (double)mean32 + prior; /* float32 + float64 -> float64 */
+                        score_is_f32 = 0;
+                    }
                 } else {
-                    connect_score = (double)mean32 + prior; /* float32 + float64 -> float64 */
+                    const double mean64 = f64_pairwise_sum(resp64, mid_num) / (double)mid_num;
+                    connect_score = 0.0 < prior ? mean64 : mean64 + prior;
                     score_is_f32 = 0;
                 }
                 const int criterion1 = (double)cnt > (double)mid_num * 0.8; /* :375 */
@@ -986,7 +1015,7 @@ int orc_py_find_humans(const float *peaks, int n_peaks, const float *paf, int H,
                     cd.j = j;
                     cd.score = connect_score;
                     cd.limb_len = limb_len;
-                    cd.overall = (half_cs + 0.25 * (double)S[2]) + 0.25 * (double)D[2]; /* :381 */
+                    cd.overall = (half_cs + 0.25 * S[2]) + 0.25 * D[2]; /* :381 */
                     cd.gen = nc;
                     cs[nc++] = cd;
                 }
@@ -1002,8 +1031,8 @@ int orc_py_find_humans(const float *peaks, int n_peaks, const float *paf, int H,
             if (used) continue;
             if (nconn[pair] >= max_conn) break;
             conn6 c6;
-            c6.src_id = (double)peaks[5 * part_idx[ps][cs[k].i] + 3];
-            c6.dst_id = (double)peaks[5 * part_idx[pd][cs[k].j] + 3];
+            c6.src_id = peaks[5 * part_idx[ps][cs[k].i] + 3];
+            c6.dst_id = peaks[5 * part_idx[pd][cs[k].j] + 3];
             c6.score = cs[k].score;
             c6.i = cs[k].i;
             c6.j = cs[k].j;
@@ -1107,4 +1136,118 @@ int orc_py_find_humans(const float *peaks, int n_peaks, const float *paf, int H,
     for (int k = 0; k < ORC_NUM_PART; k++) free(part_idx[k]);
     for (int p = 0; p < ORC_NUM_LIMB; p++) free(conns[p]);
     return n_out;
+}
+
+
+int orc_py_find_humans(const float *peaks, int n_peaks, const float *paf, int H, int W, int C, int img_height,
+                       double *persons_out, int cap, int *n_conn_out) {
+    double *pk = (double *)malloc(sizeof(double) * 5 * (size_t)(n_peaks > 0 ? n_peaks : 1));
+    for (int i = 0; i < 5 * n_peaks; i++) pk[i] = (double)peaks[i];
+    int n = py_find_humans_core(pk, n_peaks, paf, NULL, H, W, C, img_height, persons_out, cap, n_conn_out);
+    free(pk);
+    return n;
+}
+
+int orc_py_find_humans_f64(const double *peaks, int n_peaks, const double *paf_planar, int H, int W, int img_height,
+                           double *persons_out, int cap, int *n_conn_out) {
+    return py_find_humans_core(peaks, n_peaks, NULL, paf_planar, H, W, ORC_NUM_LIMB, img_height, persons_out, cap, n_conn_out);
+}
+
+/* ------------------------------------------------------------------ A10: the original (non-refactored) path
+ * predict (utils/parse_skeletons.py:180-283): per scale, the flip-averaged maps are up-sampled x4 (bicubic, :252-263),
+ * the padding is cropped (:272-273), the result is resized to the image size (:276-277) and averaged over the scales
+ * in float64 accumulators (:280-281; `heatmap / n` is a float32 division).  Planar layout here. */
+void orc_predict_accumulate(const void *net_out, int is_f16, int h, int w, int flip, int pad_down, int pad_right, int img_h,
+                            int img_w, int n_scales, double *heat_acc, double *paf_acc) {
+    const size_t plane = (size_t)h * w;
+    float *heat = (float *)malloc(sizeof(float) * ORC_NUM_HEAT * plane);
+    float *paf = (float *)malloc(sizeof(float) * ORC_NUM_LIMB * plane);
+    orc_flip_average(net_out, is_f16, h, w, flip, heat, paf);
+    const int uh = 4 * h, uw = 4 * w;
+    const int ch = uh - pad_down, cw = uw - pad_right; /* size of the scaled (unpadded) image */
+    float *up = (float *)malloc(sizeof(float) * (size_t)uh * uw);
+    float *rs = (float *)malloc(sizeof(float) * (size_t)img_h * img_w);
+    for (int c = 0; c < ORC_NUM_CH; c++) {
+        const float *src = c < ORC_NUM_LIMB ? paf + (size_t)c * plane : heat + (size_t)(c - ORC_NUM_LIMB) * plane;
+        double *acc = c < ORC_NUM_LIMB ? paf_acc + (size_t)c * img_h * img_w : heat_acc + (size_t)(c - ORC_NUM_LIMB) * img_h * img_w;
+        orc_resize_cubic(src, h, w, w, 1, up, uh, uw, uw, 1, 0.25, 0.25);
+        if (ch == img_h && cw == img_w) { /* cv2.resize returns a copy when the size does not change */
+            for (int y = 0; y < img_h; y++) memcpy(rs + (size_t)y * img_w, up + (size_t)y * uw, sizeof(float) * (size_t)img_w);
+        } else {
+            /* cv2.resize(src, (img_w, img_h)): scale = 1 / (dsize / ssize) in double */
+            orc_resize_cubic(up, ch, cw, uw, 1, rs, img_h, img_w, img_w, 1, 1.0 / ((double)img_w / (double)cw),
+                             1.0 / ((double)img_h / (double)ch));
+        }
+        for (size_t i = 0; i < (size_t)img_h * img_w; i++) acc[i] = acc[i] + (double)(rs[i] / (float)n_scales);
+    }
+    free(heat);
+    free(paf);
+    free(up);
+    free(rs);
+}
+
+/* find_peaks (utils/parse_skeletons.py:286-321): float32 cast, 3x3 / >= thre1 NMS, refine_centroid (radius 2),
+ * ids sequential over parts.  rows: [x, y, score, id, part] as doubles (coordinates are fractional here). */
+int orc_find_peaks_original(const double *heat_acc, int img_h, int img_w, float thre1, double *rows_out, int max_rows) {
+    const size_t plane = (size_t)img_h * img_w;
+    float *m = (float *)malloc(sizeof(float) * plane);
+    int *xy = (int *)malloc(sizeof(int) * 2 * plane);
+    int total = 0;
+    for (int part = 0; part < ORC_NUM_PART; part++) {
+        for (size_t i = 0; i < plane; i++) m[i] = (float)heat_acc[(size_t)part * plane + i];
+        int n = orc_find_peaks_3x3(m, img_h, img_w, thre1, xy, (int)plane);
+        for (int i = 0; i < n; i++) {
+            double o[3];
+            orc_refine_centroid(m, img_h, img_w, xy[2 * i], xy[2 * i + 1], 2, o);
+            if (total < max_rows) {
+                double *r = rows_out + (size_t)5 * total;
+                r[0] = o[0];
+                r[1] = o[1];
+                r[2] = o[2];
+                r[3] = (double)total;
+                r[4] = (double)part;
+            }
+            total++;
+        }
+    }
+    free(m);
+    free(xy);
+    return total;
+}
+
+/* cv2.resize(INTER_CUBIC) on an 8-bit image (predict :204 for scale != 1): OpenCV's fixed-point path restated --
+ * coefficients scaled by 2048 and rounded to short, integer horizontal pass, vertical pass (sum + 2^21) >> 22 with
+ * saturation (resize.cpp: HResizeCubic<uchar,int,short>, VResizeCubic + FixedPtCast<int,uchar,22>, scalar form; the
+ * SSE form of the vertical pass rounds in float and can differ by one count).  PARITY UNPINNED (OpenCV absent). */
+void orc_resize_cubic_u8(const unsigned char *src, int sh, int sw, int cn, unsigned char *dst, int dh, int dw,
+                         double scale_x, double scale_y) {
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = (int)floorf(fy);
+        fy -= (float)sy;
+        float cb[4];
+        orc_cubic_coeffs(fy, cb);
+        int ib[4];
+        for (int k = 0; k < 4; k++) ib[k] = (int)lrintf(cb[k] * 2048.0f);
+        for (int dx = 0; dx < dw; dx++) {
+            float fx = (float)((dx + 0.5) * scale_x - 0.5);
+            int sx = (int)floorf(fx);
+            fx -= (float)sx;
+            float ca[4];
+            orc_cubic_coeffs(fx, ca);
+            int ia[4];
+            for (int k = 0; k < 4; k++) ia[k] = (int)lrintf(ca[k] * 2048.0f);
+            for (int c = 0; c < cn; c++) {
+                int acc = 0;
+                for (int ky = 0; ky < 4; ky++) {
+                    const unsigned char *row = src + (size_t)clampi(sy - 1 + ky, 0, sh - 1) * sw * cn;
+                    int hsum = 0;
+                    for (int kx = 0; kx < 4; kx++) hsum += (int)row[(size_t)clampi(sx - 1 + kx, 0, sw - 1) * cn + c] * ia[kx];
+                    acc += hsum * ib[ky];
+                }
+                int v = (acc + (1 << 21)) >> 22;
+                dst[((size_t)dy * dw + dx) * cn + c] = (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+            }
+        }
+    }
 }

@@ -109,6 +109,20 @@ int orc_pipeline(orc_ctx *c, const void *net_out, int is_f16, int h, int w, int 
 int orc_py_find_humans(const float *peaks, int n_peaks, const float *paf, int H, int W, int C, int img_height,
                        double *persons_out, int cap, int *n_conn_out);
 
+/* the same on the original path's inputs: peaks as rows of 5 doubles, limb maps planar (30, H, W) float64 */
+int orc_py_find_humans_f64(const double *peaks, int n_peaks, const double *paf_planar, int H, int W, int img_height,
+                           double *persons_out, int cap, int *n_conn_out);
+
+/* ---- A10: predict's per-scale accumulation (utils/parse_skeletons.py:250-281), planar float64 accumulators
+ * heat_acc (20, img_h, img_w) and paf_acc (30, img_h, img_w), and find_peaks (:286-321). */
+void orc_predict_accumulate(const void *net_out, int is_f16, int h, int w, int flip, int pad_down, int pad_right, int img_h,
+                            int img_w, int n_scales, double *heat_acc, double *paf_acc);
+int orc_find_peaks_original(const double *heat_acc, int img_h, int img_w, float thre1, double *rows_out, int max_rows);
+
+/* cv2.resize(INTER_CUBIC) of an 8-bit interleaved image (fixed-point path; parity unpinned) */
+void orc_resize_cubic_u8(const unsigned char *src, int sh, int sw, int cn, unsigned char *dst, int dh, int dw,
+                         double scale_x, double scale_y);
+
 /* ---- A10: util.refine_centroid, utils/util.py:188-213 (float64 arithmetic like numpy on f32->f64?) ---- */
 void orc_refine_centroid(const float *map, int h, int w, int x, int y, int radius, double out_xys[3]);
 

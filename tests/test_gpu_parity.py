@@ -329,3 +329,74 @@ def test_python_twins_mode_against_reference_python(torch_cuda, post, oracle, ke
             if pid >= 0:
                 assert rec["humans"]["x"][h_, p] == jl[pid, 0] and rec["humans"]["y"][h_, p] == jl[pid, 1]
                 assert rec["humans"]["part_score"][h_, p] == jl[pid, 2]
+
+
+@pytest.mark.parametrize("people,dtype", [(3, np.float16), (8, np.float32)])
+def test_original_multiscale_path_against_oracle(torch_cuda, oracle, people, dtype):
+    """A10 / config 5: three scales accumulated at image resolution (predict), find_peaks, Python twins on float64 maps.
+    GPU vs the oracle's restatement: accumulators within 1e-6 (identical operation order: expected equal), peaks and
+    persons identical in ids; fractional coordinates / scores within 1e-4."""
+    from posepaf import synth
+    from posepaf.api import PosePostProcessor
+    from posepaf.original_path import OriginalPathProcessor, record_float_coords
+    torch = torch_cuda
+    IMG = 256                                             # image 256x256; scales 0.5, 1.0, 1.5 -> 128, 256, 384
+    # scale 0.5: image 128 -> pad to 128 (32x32 map, no pad); 1.0: 256 (64x64); 1.5: 384 (96x96)
+    sizes = [(32, 32, 0.5), (64, 64, 1.0), (96, 96, 1.5)]
+    outs, _ = synth.make_scene_at_scales(people, 321 + people, sizes, dtype=dtype, img=IMG)
+    post = PosePostProcessor(max_batch=2, max_h=96, max_w=96, max_peaks_per_part=64)
+    proc = OriginalPathProcessor(post, IMG, IMG, 2)
+    heat = np.zeros((20, IMG, IMG)); paf = np.zeros((30, IMG, IMG))
+    proc.reset()
+    for o, (h, w, sc) in zip(outs, sizes):
+        both = np.stack([o, o])                           # batch of two identical images
+        proc.accumulate(torch.from_numpy(both).cuda(), 0, 0, len(sizes))
+        oracle.predict_accumulate(o, 0, 0, IMG, IMG, len(sizes), heat, paf)
+    got_heat = proc.heat_acc.cpu().numpy()
+    got_paf = proc.paf_acc.cpu().numpy()
+    assert np.array_equal(got_heat[0], got_heat[1])
+    assert np.allclose(got_heat[0], heat, rtol=0, atol=1e-6) and np.allclose(got_paf[0], paf, rtol=0, atol=1e-6)
+    assert np.array_equal(got_heat[0], heat) and np.array_equal(got_paf[0], paf)
+    recs = np.frombuffer(proc.finish(2).cpu().numpy().tobytes(), dtype=None) if False else None
+    from posepaf.api import records_to_numpy
+    recs = records_to_numpy(proc.finish(2))
+    rows = oracle.find_peaks_original(heat, 0.1)
+    persons, ncn = oracle.py_find_humans_f64(rows, paf, IMG)
+    for rec in recs:
+        assert rec["status"] & 32                          # PP_ST_FLOAT_COORDS
+        assert rec["n_peaks"] == len(rows)
+        n = int(rec["n_humans"])
+        assert n == len(persons)
+        assert np.array_equal(rec["humans"]["peak_id"][:n], persons[:, :18, 0].astype(np.int32))
+        assert np.array_equal(rec["humans"]["n_parts"][:n], persons[:, 19, 0].astype(np.int32))
+        assert np.allclose(rec["humans"]["score"][:n], persons[:, 18, 0] / persons[:, 19, 0], rtol=0, atol=SCORE_TOL)
+        fx, fy = record_float_coords(rec)
+        for h_ in range(n):
+            for p in range(18):
+                pid = rec["humans"]["peak_id"][h_, p]
+                if pid >= 0:
+                    assert abs(fx[h_, p] - rows[pid, 0]) < 1e-4 and abs(fy[h_, p] - rows[pid, 1]) < 1e-4
+    post.close()
+
+
+def test_original_path_padding_crop_and_image_resize(torch_cuda, oracle):
+    """scale whose padded size differs from the scaled size (crop :272-273) and the uint8 image resize kernel."""
+    from posepaf import synth
+    from posepaf.api import PosePostProcessor
+    from posepaf.original_path import OriginalPathProcessor, resize_images_u8
+    torch = torch_cuda
+    img = np.random.default_rng(9).integers(0, 256, (2, 200, 264, 3), dtype=np.uint8)
+    for scale in (0.5, 1.5):
+        got = resize_images_u8(torch.from_numpy(img).cuda(), scale).cpu().numpy()
+        for b in range(2):
+            assert np.array_equal(got[b], oracle.resize_u8(img[b], scale, scale))
+    # image 200x264 at scale 1: padded to 256x320 -> feature map 64x80, crop 56 rows / 56 cols of the x4 upsample
+    net = synth.make_net_output(4, 55, h=64, w=80, dtype=np.float16)
+    post = PosePostProcessor(max_batch=1, max_h=80, max_w=80, max_peaks_per_part=64)
+    proc = OriginalPathProcessor(post, 200, 264, 1)
+    proc.reset()
+    proc.accumulate(torch.from_numpy(net).cuda()[None], 56, 56, 1)
+    heat = np.zeros((20, 200, 264)); paf = np.zeros((30, 200, 264))
+    oracle.predict_accumulate(net, 56, 56, 200, 264, 1, heat, paf)
+    assert np.array_equal(proc.heat_acc.cpu().numpy()[0], heat) and np.array_equal(proc.paf_acc.cpu().numpy()[0], paf)
+    post.close()
