@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--postproc-only", action="store_true", help="time only K_A..K_C (profiling aid)")
     ap.add_argument("--plain-model", action="store_true", help="unfused nn.Module forward instead of the fused one")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--multiscale", action="store_true",
+                    help="BASELINE configs[4]: original path, scale search {0.5, 1.0, 1.5} x 512 + flip, float64 accumulation")
     return ap.parse_args()
 
 
@@ -85,6 +87,72 @@ def cpu_baseline(uniq_scenes, seconds):
             "sample": f"{n} images ({len(uniq_scenes)} scenes of {min(SCENE_PEOPLE)}-{max(SCENE_PEOPLE)} people, cycled) "
                       f"in {dt:.1f} s; post-processing only (flip-average, NMS+refine, x4 limb upsample, process_paf); "
                       "network forward excluded"}
+
+
+def bench_multiscale(a, world, rank, dev, dist, backend, model, post, images):
+    """configs[4]: predict's scale search (0.5, 1.0, 1.5) with flip, per-scale maps up-sampled, resized to the image and
+    accumulated in float64 in HBM, then find_peaks + the Python-twin matching at image resolution."""
+    from posepaf import synth
+    from posepaf._lib import RECORD_BYTES
+    from posepaf.api import records_to_numpy
+    from posepaf.original_path import OriginalPathProcessor, resize_images_u8
+    from posepaf.pipeline import preprocess_batch
+    B = a.batch
+    mult = (0.5, 1.0, 1.5)
+    sizes = [(64, 64, 0.5), (128, 128, 1.0), (192, 192, 1.5)]
+    proc = OriginalPathProcessor(post, IMG, IMG, B)
+    uniq = [synth.make_scene_at_scales(p, 9100 + i, sizes)[0] for i, p in enumerate(SCENE_PEOPLE)]
+    inject = [torch.from_numpy(np.stack([uniq[i % len(uniq)][k] for i in range(B)])).to(dev) for k in range(len(sizes))]
+    scale = torch.tensor(1e-3, dtype=torch.float16, device=dev)
+    gdev = dev if backend == "nccl" else torch.device("cpu")
+    gathered = torch.empty(world * B * RECORD_BYTES, dtype=torch.uint8, device=gdev) if world > 1 else None
+
+    def step():
+        with torch.no_grad():
+            proc.reset()
+            for k, sc in enumerate(mult):
+                scaled = resize_images_u8(images, sc)
+                x = preprocess_batch(scaled, True, torch.float16)
+                maps = model(x).view(B, 2, 50, sizes[k][0], sizes[k][1])
+                maps = torch.addcmul(inject[k], maps, scale)
+                proc.accumulate(maps, 0, 0, len(mult))
+            rec = proc.finish(B)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, rec if backend == "nccl" else rec.cpu())
+        return rec
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        rec = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        rec = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=gdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    recs = records_to_numpy(rec)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "end-to-end images/sec at 512x512, multi-scale", "value": world * B * a.steps / dt, "unit": "images/sec",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+            "data": "synthetic (random-init IMHN weights, random uint8 images, the same synthetic people injected at every scale)",
+            "config": {"workload": "configs[4]: original path, scales {0.5,1.0,1.5} x 512 + flip, float64 accumulation at image "
+                                   "resolution in HBM, find_peaks + Python-twin matching", "images_per_gpu_per_step": B,
+                       "people_per_scene": list(SCENE_PEOPLE), "parallelism": f"image-sharded x{world}"},
+            "humans_found_in_batch": int(recs["n_humans"].sum()), "status_or": int(np.bitwise_or.reduce(recs["status"]))}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -130,6 +198,9 @@ def main():
 
     scale = torch.tensor(1e-3, dtype=torch.float16, device=dev)
     static_images = images.clone()
+
+    if a.multiscale:
+        return bench_multiscale(a, world, rank, dev, dist, backend, model, post, images)
 
     def body():
         if a.postproc_only:
