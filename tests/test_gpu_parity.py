@@ -400,3 +400,69 @@ def test_original_path_padding_crop_and_image_resize(torch_cuda, oracle):
     oracle.predict_accumulate(net, 56, 56, 200, 264, 1, heat, paf)
     assert np.array_equal(proc.heat_acc.cpu().numpy()[0], heat) and np.array_equal(proc.paf_acc.cpu().numpy()[0], paf)
     post.close()
+
+
+def test_capacity_flags_per_image_sizes_and_graph_capture(torch_cuda, oracle):
+    """Edge cases of the native path: peak-capacity overflow is flagged (not silent), per-image min_img_size from a
+    device array, a 128-peaks-per-part context, and hipGraph capture/replay of pp_process_batch."""
+    from posepaf import synth
+    from posepaf.api import PosePostProcessor, records_to_numpy
+    torch = torch_cuda
+    # (1) overflow: a tiny capacity on a 12-people scene
+    net = synth.make_net_output(12, 3, dtype=np.float16)
+    small = PosePostProcessor(max_batch=1, max_h=128, max_w=128, max_peaks_per_part=4)
+    rec = small.process(torch.from_numpy(net).cuda()[None], 512)[0]
+    assert rec["status"] & 1                     # PP_ST_PEAK_OVERFLOW
+    with pytest.raises(Exception):
+        small.read_peaks(0)                      # truncated joint list is refused loudly
+    small.close()
+    # (2) per-image min_img_size (device array) == separate runs with scalar sizes
+    post = PosePostProcessor(max_batch=4, max_h=128, max_w=128, max_peaks_per_part=128)
+    nets = np.stack([synth.make_net_output(6, 60 + i, dtype=np.float16) for i in range(4)])
+    dev = torch.from_numpy(nets).cuda()
+    sizes = [512, 256, 128, 64]
+    mis = torch.tensor(sizes, dtype=torch.int32, device="cuda")
+    recs = records_to_numpy(post.process_async(dev, 999, True, min_img_size_dev=mis))
+    for i, s in enumerate(sizes):
+        want = oracle.pipeline(nets[i], s)
+        n = int(recs[i]["n_humans"])
+        assert n == len(want["ids"]) and np.array_equal(recs[i]["humans"]["peak_id"][:n], want["ids"])
+        assert np.array_equal(recs[i]["humans"]["score"][:n], want["scores"])
+    # (3) capture into a HIP graph and replay on new data
+    static_in = dev.clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        post.process_async(static_in, 512, True)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = post.process_async(static_in, 512, True)
+    other = np.stack([synth.make_net_output(5, 90 + i, dtype=np.float16) for i in range(4)])
+    static_in.copy_(torch.from_numpy(other).cuda())
+    g.replay()
+    got = records_to_numpy(out)
+    for i in range(4):
+        want = oracle.pipeline(other[i], 512)
+        n = int(got[i]["n_humans"])
+        assert n == len(want["ids"]) and np.array_equal(got[i]["humans"]["peak_id"][:n], want["ids"])
+    post.close()
+
+
+def test_python_twin_mode_batched_and_fp32(torch_cuda, oracle):
+    from posepaf import synth
+    from posepaf.api import PosePostProcessor
+    torch = torch_cuda
+    post = PosePostProcessor(max_batch=3, max_h=128, max_w=128, max_peaks_per_part=64)
+    nets = [synth.make_net_output(p, 700 + p, dtype=np.float32) for p in (2, 9, 17)]
+    recs = post.process_py(torch.from_numpy(np.stack(nets)).cuda(), 512)
+    for net, rec in zip(nets, recs):
+        heat, paf = oracle.flip_average(net)
+        jl, _ = oracle.heatmap_nms(heat)
+        persons, ncn = oracle.py_find_humans(jl, oracle.upsample4_hwc(paf), 512)
+        n = int(rec["n_humans"])
+        assert n == len(persons) and rec["n_connections"] == int(ncn.sum())
+        assert np.array_equal(rec["humans"]["peak_id"][:n], persons[:, :18, 0].astype(np.int32))
+        assert np.allclose(rec["humans"]["score"][:n], persons[:, 18, 0] / persons[:, 19, 0], rtol=0, atol=SCORE_TOL)
+    post.close()
