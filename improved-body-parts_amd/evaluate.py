@@ -43,13 +43,18 @@ def parse():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--dump_name", default="results.json")
     ap.add_argument("--people", type=int, nargs="*", default=[1, 2, 3, 4, 6, 8, 10, 5])
+    ap.add_argument("--scales", type=float, nargs="*", default=None,
+                    help="without --run_refactor: predict's `multiplier` list (the reference hard-codes [1.0], "
+                         "utils/parse_skeletons.py:188); e.g. 0.5 1.0 1.5 for BASELINE config 5")
     return ap.parse_args()
 
 
 def main():
     a = parse()
-    if not a.run_refactor:
-        raise SystemExit("only the refactored path (--run_refactor, with or without --run_cpp) is implemented here")
+    original = not a.run_refactor   # evaluate.py:81-84: predict + find_peaks + find_connections + find_humans
+    if original and a.run_cpp:
+        raise SystemExit("--run_cpp only exists on the refactored path (evaluate.py:97-129)")
+    scales = a.scales or [1.0]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -111,15 +116,47 @@ def main():
     hp, wp = -(-H // 64) * 64 // 4, -(-W // 64) * 64 // 4
     post = PosePostProcessor(max_batch=B, max_h=hp, max_w=wp, max_peaks_per_part=64, device=local)
     pipe = PosePipeline(model, post)
+    proc = None
+    if original:
+        from posepaf.original_path import OriginalPathProcessor, record_float_coords, resize_images_u8, scaled_size
+        from posepaf.pipeline import preprocess_batch
+        proc = OriginalPathProcessor(post, H, W, B)
     local_recs = torch.zeros(S_pad * RECORD_BYTES, dtype=torch.uint8, device=dev)
     scale = torch.tensor(1e-3, dtype=torch.float16, device=dev)
 
+    # untimed warm-up on zeros: MIOpen's per-shape algorithm search happens on a shape's first call
+    with torch.no_grad():
+        warm = torch.zeros((B, H, W, 3), dtype=torch.uint8, device=dev)
+        if original:
+            for sc in scales:
+                model(preprocess_batch(resize_images_u8(warm, float(sc)), True, torch.float16))
+        else:
+            pipe.forward_maps(warm)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for b0 in range(0, len(mine), B):
         idx = mine[b0:b0 + B]
         imgs = np.stack([load(int(i)) for i in idx] + [np.zeros((H, W, 3), np.uint8)] * (B - len(idx)))
         dev_imgs = torch.from_numpy(imgs).to(dev, non_blocking=True)
+        if original:
+            with torch.no_grad():
+                proc.reset()
+                for sc in scales:
+                    scaled = resize_images_u8(dev_imgs, float(sc))
+                    sh, sw = scaled.shape[1:3]
+                    x = preprocess_batch(scaled, True, torch.float16)
+                    ph, pw = x.shape[1:3]
+                    maps = model(x).contiguous().view(B, 2, 50, ph // 4, pw // 4)
+                    if inject_for is not None:   # the same synthetic people, rendered at this scale
+                        sizes = [(ph // 4, pw // 4, float(sc))]
+                        inj = np.stack([synth.make_scene_at_scales(a.people[int(i) % len(a.people)], 20_000 + int(i) % 64, sizes,
+                                                                   img=H)[0][0] for i in idx] +
+                                       [np.zeros((2, 50, ph // 4, pw // 4), np.float16)] * (B - len(idx)))
+                        maps = torch.addcmul(torch.from_numpy(inj).to(dev), maps, scale)
+                    proc.accumulate(maps, ph - sh, pw - sw, len(scales))
+                rec = proc.finish(B)
+            local_recs[b0 * RECORD_BYTES:(b0 + B) * RECORD_BYTES].copy_(rec)
+            continue
         maps = pipe.forward_maps(dev_imgs)
         if inject_for is not None:
             inj = np.stack([inject_for(int(i))[0] for i in idx] + [np.zeros((2, 50, hp, wp), np.float16)] * (B - len(idx)))
@@ -139,12 +176,18 @@ def main():
     if rank == 0:
         results, dts = [], {}
         for i, rec in enumerate(merged):
+            if int(rec["status"]) & 32:      # PP_ST_FLOAT_COORDS (original path): x / y are float32 bit patterns
+                rec = rec.copy()
+                fx, fy = rec["humans"]["x"].view(np.float32), rec["humans"]["y"].view(np.float32)
+                rec["humans"]["x"], rec["humans"]["y"] = np.rint(fx).astype(np.int32), np.rint(fy).astype(np.int32)
             humans = coco.humans_from_record(rec)
             res = coco.coco_results(image_ids[i], humans)     # evaluate.py:182-209
             results.extend(res)
             dts[image_ids[i]] = [{"keypoints": r["keypoints"], "score": r["score"]} for r in res]
             if inject_for is not None:
-                gts[image_ids[i]] = oks_eval.gt_from_synth_joints(inject_for(i)[1])
+                joints = synth.make_scene_at_scales(a.people[i % len(a.people)], 20_000 + i % 64, [(8, 8, 1.0)], img=H)[1] \
+                    if original else inject_for(i)[1]
+                gts[image_ids[i]] = oks_eval.gt_from_synth_joints(joints)
         with open(a.dump_name, "w") as f:
             json.dump(results, f)
         summary = {"images": int(n_images), "world": world, "images_per_sec_rank0": len(mine) / dt_local,
