@@ -553,34 +553,6 @@ struct StdSortGE {
         put(i, get(j));
         put(j, t);
     }
-    __device__ void unguarded_linear_insert(int last) {
-        const SortElem val = get(last);
-        int next = last - 1;
-        while (true) {
-            if (next < 0) {
-                oob = true;
-                break;
-            }
-            const SortElem nx = get(next);
-            if (!ge(val, nx)) break;
-            put(last, nx);
-            last = next;
-            --next;
-        }
-        put(last, val);
-    }
-    __device__ void insertion_sort(int first, int last) {
-        if (first == last) return;
-        for (int i = first + 1; i != last; ++i) {
-            const SortElem val = get(i);
-            if (ge(val, get(first))) {
-                for (int k = i; k > first; --k) put(k, get(k - 1));
-                put(first, val);
-            } else {
-                unguarded_linear_insert(i);
-            }
-        }
-    }
     __device__ void push_heap(int first, int hole, int top, SortElem value) {
         int parent = (hole - 1) / 2;
         while (hole > top && ge(get(first + parent), value)) {
@@ -659,7 +631,8 @@ struct StdSortGE {
         }
     }
     // stack: LDS scratch of 3*kSortStack ints (explicit form of __introsort_loop's recursion)
-    __device__ void run(int *stk) {
+    // the __introsort_loop part of std::sort: partitions (and the heapsort fallback) down to pieces of <= 16 elements
+    __device__ void run_partitions(int *stk) {
         oob = false;
         if (n <= 0) return;
         int lg = 0;
@@ -695,12 +668,11 @@ struct StdSortGE {
                 last = cut;
             }
         }
-        if (n > 16) {  // __final_insertion_sort
-            insertion_sort(0, 16);
-            for (int i = 16; i < n; ++i) unguarded_linear_insert(i);
-        } else {
-            insertion_sort(0, n);
-        }
+        // __final_insertion_sort is NOT emulated step by step: an insertion sort with `>=` puts every element just
+        // after the last strictly greater one, i.e. in front of all equal ones, whatever the distances -- so its
+        // result is "descending key, ties in REVERSE of their order in the array as the partitioning left it".
+        // The caller computes that in parallel from the post-partition array (and the out-of-bounds condition of
+        // the unguarded inserts: an element at position >= 16 with no strictly greater element before it).
     }
 };
 
@@ -866,13 +838,28 @@ __device__ void connect_limb(const Sampler &smp, const LimbLds &L, int nA, int n
         for (int t = threadIdx.x; t < n; t += kThreads) L.order[t] = t;
         __syncthreads();
         if (threadIdx.x == 0) {
-            LdsSortAcc acc{L.key, L.order};  // sorted in place: the generation-indexed keys are no longer needed
+            LdsSortAcc acc{L.key, L.order};  // permuted in place: the generation-indexed keys are no longer needed
             StdSortGE<LdsSortAcc> srt(acc, n);
-            srt.run(s_stack);
+            srt.run_partitions(s_stack);
             if (srt.oob) s_oob = 1;
         }
         __syncthreads();
-        for (int r = threadIdx.x; r < n; r += kThreads) L.rank[L.order[r]] = r;
+        // final insertion sort in closed form, one thread per position p of the post-partition array
+        bool oob = false;
+        for (int p = threadIdx.x; p < n; p += kThreads) {
+            const float kp = L.key[p];
+            int gt = 0, eq_after = 0, gt_before = 0;
+            for (int q = 0; q < n; q++) {
+                const float kq = L.key[q];  // broadcast read
+                gt += kq > kp;
+                eq_after += (kq == kp) && (q > p);
+                gt_before += (kq > kp) && (q < p);
+            }
+            L.rank[L.order[p]] = gt + eq_after;
+            oob |= (p >= 16) && (gt_before == 0);  // the reference's unguarded insert would run off the array
+        }
+        if (__syncthreads_or(oob) && threadIdx.x == 0) s_oob = 1;
+        for (int t = threadIdx.x; t < n; t += kThreads) L.order[L.rank[t]] = t;
     } else {
         for (int t = threadIdx.x; t < n; t += kThreads) L.order[L.rank[t]] = t;
     }
