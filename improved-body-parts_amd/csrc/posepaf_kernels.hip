@@ -657,8 +657,10 @@ struct StdSortGE {
                 --depth;
                 const int mid = first + (last - first) / 2;
                 move_median_to_first(first, first + 1, mid, last - 1);
-                int cut = unguarded_partition(first + 1, last, first);
-                if (cut > last) cut = last;  // only after an out-of-bounds scan
+                // NOTE: with the non-strict comparator the left scan may run past `last` (every element of the range
+                // >= pivot) and stop on an element of a neighbouring range; libstdc++ then simply continues with
+                // [first, cut) -- reproduced as is (cut <= n always: the scan stops at the array end, flagged oob)
+                const int cut = unguarded_partition(first + 1, last, first);
                 if (sp < kSortStack) {
                     stk[3 * sp] = cut;
                     stk[3 * sp + 1] = last;
@@ -676,36 +678,45 @@ struct StdSortGE {
     }
 };
 
-// Scores one (a, b) peak pair: pafprocess.cpp:66-106 + get_paf_scores :311-327.
+// One (a, b) peak pair: pafprocess.cpp:66-106 + get_paf_scores :311-327, split so that the samples can be taken in two
+// instalments (see connect_limb): geometry, samples [i0, i1) accumulated IN INDEX ORDER, final criteria.
+struct PairGeom {
+    float vec_length, step_x, step_y;
+    int num_steps;
+};
+__device__ __forceinline__ bool pair_geom(int ax, int ay, int bx, int by, PairGeom &g) {
+    const float vx = (float)(bx - ax), vy = (float)(by - ay);
+    g.vec_length = sqrtf(__fadd_rn(__fmul_rn(vx, vx), __fmul_rn(vy, vy)));  // :70
+    if ((double)g.vec_length < 1e-12) return false;                          // :71
+    int n = (int)((double)__fadd_rn(g.vec_length, 1.0f) + 0.5);              // round2int, :73, :329
+    g.num_steps = n > 20 ? 20 : n;                                           // STEP_PAF
+    g.step_x = vx / (float)(g.num_steps - 1);                                // :314-315
+    g.step_y = vy / (float)(g.num_steps - 1);
+    return true;
+}
 template <typename Sampler>
-__device__ __forceinline__ bool score_pair(const Sampler &smp, int ax, int ay, float as, int bx, int by, float bs,
-                                           int min_img_size, float *c2_out, float *overall_out, float *len_out) {
-    const int dxi = bx - ax, dyi = by - ay;
-    const float vx = (float)dxi, vy = (float)dyi;
-    const float vec_length = sqrtf(__fadd_rn(__fmul_rn(vx, vx), __fmul_rn(vy, vy)));  // :70
-    if ((double)vec_length < 1e-12) return false;                                      // :71
-    int num_steps = (int)((double)__fadd_rn(vec_length, 1.0f) + 0.5);                  // round2int, :73, :329
-    if (num_steps > 20) num_steps = 20;                                                // STEP_PAF
-    const float step_x = vx / (float)(num_steps - 1);                                  // :314-315
-    const float step_y = vy / (float)(num_steps - 1);
-    float scores = 0.0f;
-    int criterion1 = 0;
-    for (int i = 0; i < num_steps; i++) {
-        const int lx = (int)((double)__fadd_rn((float)ax, __fmul_rn((float)i, step_x)) + 0.5);  // :318-319
-        const int ly = (int)((double)__fadd_rn((float)ay, __fmul_rn((float)i, step_y)) + 0.5);
+__device__ __forceinline__ void pair_samples(const Sampler &smp, const PairGeom &g, int ax, int ay, int i0, int i1, float &scores,
+                                             int &criterion1) {
+    for (int i = i0; i < i1; i++) {
+        const int lx = (int)((double)__fadd_rn((float)ax, __fmul_rn((float)i, g.step_x)) + 0.5);  // :318-319
+        const int ly = (int)((double)__fadd_rn((float)ay, __fmul_rn((float)i, g.step_y)) + 0.5);
         const float s = smp.at(lx, ly);
         scores = __fadd_rn(scores, s);  // :86
         if (s > 0.1f) criterion1 += 1;  // THRESH_PAF_SCORE
     }
-    double prior = 0.5 * (double)min_img_size / (double)vec_length - 1.0;  // :92
-    if (!(prior < 0.0)) prior = 0.0;                                        // std::min(0.0, prior)
-    const float criterion2 = (float)((double)(scores / (float)num_steps) + prior);
-    const float min_num_steps = __fmul_rn((float)num_steps, 0.8f);  // :93 THRESH_PAF_STEP_RATIO
+}
+// smallest count that passes `criterion1 > num_steps * 0.8f` (:93-95)
+__device__ __forceinline__ int pair_min_count(int num_steps) { return (int)floorf(__fmul_rn((float)num_steps, 0.8f)) + 1; }
+__device__ __forceinline__ bool pair_finish(const PairGeom &g, float scores, int criterion1, float as, float bs, int min_img_size,
+                                            float *c2_out, float *overall_out) {
+    double prior = 0.5 * (double)min_img_size / (double)g.vec_length - 1.0;  // :92
+    if (!(prior < 0.0)) prior = 0.0;                                          // std::min(0.0, prior)
+    const float criterion2 = (float)((double)(scores / (float)g.num_steps) + prior);
+    const float min_num_steps = __fmul_rn((float)g.num_steps, 0.8f);  // :93 THRESH_PAF_STEP_RATIO
     if (!((float)criterion1 > min_num_steps && criterion2 > 0.0f)) return false;  // :95
     // :96-98  PAF_OUT_WEIGHTS = {0.5, 0.25, 0.25}
     *overall_out = __fadd_rn(__fadd_rn(__fmul_rn(0.5f, criterion2), __fmul_rn(0.25f, as)), __fmul_rn(0.25f, bs));
     *c2_out = criterion2;
-    *len_out = vec_length;
     return true;
 }
 
@@ -768,18 +779,76 @@ __device__ void connect_limb(const Sampler &smp, const LimbLds &L, int nA, int n
     const int npairs = nA * nB;
     int ncand = 0;  // uniform across the workgroup
     int buf = 0;
-    for (int base = 0; base < npairs; base += kThreads, buf ^= 1) {
-        const int p = base + threadIdx.x;
-        bool ok = false;
-        float c2 = 0.f, overall = 0.f, len = 0.f;
-        int ia = 0, ib = 0;
-        if (p < npairs) {
-            ia = p / nB;  // generation order of the reference: a outer, b inner (:61-64)
-            ib = p - ia * nB;
-            ok = score_pair(smp, L.ax[ia], L.ay[ia], L.as[ia], L.bx[ib], L.by[ib], L.bs[ib], min_img_size, &c2, &overall,
-                            &len);
+    // Scoring in two instalments.  (1) Every pair takes its first kFirst samples; a pair whose misses (samples <= 0.1)
+    // already exceed what `criterion1 > 0.8 n` (:93-95) tolerates can never be accepted and is dropped -- most of the
+    // nA x nB pairs join different people and die here.  (2) The survivors of several rounds are packed together (in
+    // generation order) and finish their remaining samples with all lanes busy, continuing the SAME running sum, so
+    // the float additions happen in the reference's order.  The survivor list lives in the rank/order/state arrays,
+    // which are not needed before the ranking step.
+    constexpr int kFirst = 8;
+    int *sv_pair = L.rank;
+    float *sv_sum = reinterpret_cast<float *>(L.order);
+    int *sv_cnt = L.state;
+    int nsv = 0;  // uniform
+    auto flush = [&]() {
+        for (int sb = 0; sb < nsv; sb += kThreads, buf ^= 1) {
+            const int sidx = sb + threadIdx.x;
+            bool ok = false;
+            float c2 = 0.f, overall = 0.f, len = 0.f;
+            int ia = 0, ib = 0;
+            if (sidx < nsv) {
+                const int p = sv_pair[sidx];
+                ia = p / nB;
+                ib = p - ia * nB;
+                PairGeom g;
+                pair_geom(L.ax[ia], L.ay[ia], L.bx[ib], L.by[ib], g);
+                float scores = sv_sum[sidx];
+                int c1 = sv_cnt[sidx];
+                if (g.num_steps > kFirst) pair_samples(smp, g, L.ax[ia], L.ay[ia], kFirst, g.num_steps, scores, c1);
+                ok = pair_finish(g, scores, c1, L.as[ia], L.bs[ib], min_img_size, &c2, &overall);
+                len = g.vec_length;
+            }
+            const unsigned long long m = __ballot(ok);
+            if (lane == 0) s_wcnt[buf][wave] = __popcll(m);
+            __syncthreads();
+            int before = 0, all = 0;
+#pragma unroll
+            for (int k = 0; k < kWaves; k++) {
+                const int c = s_wcnt[buf][k];
+                if (k < wave) before += c;
+                all += c;
+            }
+            if (ok) {
+                const int pos = ncand + before + __popcll(m & lanemask_lt());
+                if (pos < cap) {
+                    L.key[pos] = overall;
+                    L.c_score[pos] = c2;
+                    L.c_len[pos] = len;
+                    L.c_idx[pos] = (unsigned)ia | ((unsigned)ib << 16);
+                }
+            }
+            ncand += all;
         }
-        const unsigned long long m = __ballot(ok);
+        __syncthreads();  // the survivor arrays may be overwritten from here on
+        nsv = 0;
+    };
+    for (int base = 0; base < npairs; base += kThreads, buf ^= 1) {
+        if (nsv + kThreads > cap) flush();
+        const int p = base + threadIdx.x;
+        bool alive = false;
+        float scores = 0.0f;
+        int c1 = 0;
+        if (p < npairs) {
+            const int ia = p / nB;  // generation order of the reference: a outer, b inner (:61-64)
+            const int ib = p - ia * nB;
+            PairGeom g;
+            if (pair_geom(L.ax[ia], L.ay[ia], L.bx[ib], L.by[ib], g)) {
+                const int k1 = g.num_steps < kFirst ? g.num_steps : kFirst;
+                pair_samples(smp, g, L.ax[ia], L.ay[ia], 0, k1, scores, c1);
+                alive = (k1 - c1) <= g.num_steps - pair_min_count(g.num_steps);
+            }
+        }
+        const unsigned long long m = __ballot(alive);
         if (lane == 0) s_wcnt[buf][wave] = __popcll(m);
         __syncthreads();
         int before = 0, all = 0;
@@ -789,17 +858,16 @@ __device__ void connect_limb(const Sampler &smp, const LimbLds &L, int nA, int n
             if (k < wave) before += c;
             all += c;
         }
-        if (ok) {
-            const int pos = ncand + before + __popcll(m & lanemask_lt());
-            if (pos < cap) {
-                L.key[pos] = overall;
-                L.c_score[pos] = c2;
-                L.c_len[pos] = len;
-                L.c_idx[pos] = (unsigned)ia | ((unsigned)ib << 16);
-            }
+        if (alive) {
+            const int pos = nsv + before + __popcll(m & lanemask_lt());
+            sv_pair[pos] = p;
+            sv_sum[pos] = scores;
+            sv_cnt[pos] = c1;
         }
-        ncand += all;
+        nsv += all;
     }
+    __syncthreads();
+    flush();
     unsigned st = 0;
     if (ncand > cap) {
         st |= PP_ST_CAND_OVERFLOW;

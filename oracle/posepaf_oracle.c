@@ -537,8 +537,9 @@ static void ls_introsort_loop(cand_t *b, int first, int last, int depth_limit, i
         --depth_limit;
         int mid = first + (last - first) / 2;
         ls_move_median_to_first(b, first, first + 1, mid, last - 1);
+        /* with the non-strict comparator the left scan may run past `last` and stop on an element of a neighbouring
+         * range; libstdc++ then continues with [first, cut) -- reproduced as is (cut <= n: the scan stops at the array end) */
         int cut = ls_unguarded_partition(b, first + 1, last, first, n);
-        if (cut > last) cut = last; /* only after an out-of-bounds scan */
         ls_introsort_loop(b, cut, last, depth_limit, n);
         last = cut;
     }
