@@ -1113,7 +1113,7 @@ constexpr int kMaxSkel = 256;
 constexpr int kSkelStride = 21;  // 20 entries, odd stride: the per-lane column reads of the scan are conflict-free
 
 __host__ __device__ inline size_t assemble_lds_bytes(int maxp) {
-    return (size_t)kMaxSkel * kSkelStride * 8 + (size_t)PP_NUM_PART * maxp * 16 + (size_t)PP_NUM_LIMB * maxp * 16;
+    return (size_t)kMaxSkel * kSkelStride * 8 + (size_t)PP_NUM_PART * maxp * 16 + (size_t)PP_NUM_LIMB * maxp * 16 + 16 * (size_t)maxp;
 }
 
 __global__ __launch_bounds__(64) void k_assemble(int maxp, int explicit_ids, const float4 *__restrict__ peaks,
@@ -1130,94 +1130,310 @@ __global__ __launch_bounds__(64) void k_assemble(int maxp, int explicit_ids, con
     float *line_s = reinterpret_cast<float *>(line_y + ntab);
     int *ids = reinterpret_cast<int *>(line_s + ntab);                      // [18][maxp] peak id of (part, rank)
     float4 *s_conn = reinterpret_cast<float4 *>(ids + ntab);                // all connections, limb-major, compact
+    int *s_own1 = reinterpret_cast<int *>(s_conn + PP_NUM_LIMB * maxp);     // [maxp] skeleton holding peak r at part 1 / 2
+    int *s_own2 = s_own1 + maxp;
+    int *s_cb1 = s_own2 + maxp;                                             // [maxp] connection using peak r as end point 1 / 2
+    int *s_cb2 = s_cb1 + maxp;
     __shared__ int s_off[PP_NUM_PART + 1];
     __shared__ int s_cnt[PP_NUM_PART];
     __shared__ int s_coff[PP_NUM_LIMB + 1];
-    __shared__ int s_merge;
+    __shared__ int s_conf[64];  // per connection of the current limb: shares a skeleton with another connection
 
     const int *cnt_g = counts + img * PP_NUM_PART;
     const float4 *pk_g = peaks + (size_t)img * PP_NUM_PART * maxp;
-    if (lane == 0) {
-        int run = 0;
-        for (int k = 0; k < PP_NUM_PART; k++) {
-            int c = cnt_g[k];
-            c = c < maxp ? c : maxp;
-            s_cnt[k] = c;
-            s_off[k] = run;
-            run += c;
+    long long *stamps = d_stamps;
+    long long seq_cycles = 0, seq_limbs = 0;
+    stamp(stamps, img, 0);
+    {  // bucket offsets: one count per lane, wave prefix sums (no serial chain of global loads)
+        int c = lane < PP_NUM_PART ? cnt_g[lane] : 0;
+        int cc = lane < PP_NUM_LIMB ? conn_counts[img * PP_NUM_LIMB + lane] : 0;
+        c = c < maxp ? c : maxp;
+        cc = cc < maxp ? cc : maxp;
+        int inc = c, cinc = cc;
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) {
+            const int t = __shfl_up(inc, d), ct = __shfl_up(cinc, d);
+            if (lane >= d) {
+                inc += t;
+                cinc += ct;
+            }
         }
-        s_off[PP_NUM_PART] = run;
-        run = 0;
-        for (int l = 0; l < PP_NUM_LIMB; l++) {
-            s_coff[l] = run;
-            int c = conn_counts[img * PP_NUM_LIMB + l];
-            run += c < maxp ? c : maxp;
+        if (lane < PP_NUM_PART) {
+            s_cnt[lane] = c;
+            s_off[lane] = inc - c;
+            if (lane == PP_NUM_PART - 1) s_off[PP_NUM_PART] = inc;
         }
-        s_coff[PP_NUM_LIMB] = run;
+        if (lane < PP_NUM_LIMB) {
+            s_coff[lane] = cinc - cc;
+            if (lane == PP_NUM_LIMB - 1) s_coff[PP_NUM_LIMB] = cinc;
+        }
     }
     __syncthreads();
     const int n_peaks = s_off[PP_NUM_PART];
-    for (int part = 0; part < PP_NUM_PART; part++) {  // pafprocess.cpp:43-48 flatten in part order
-        const int c = s_cnt[part], o = s_off[part];
-        for (int r = lane; r < c; r += 64) {
+    {  // pafprocess.cpp:43-48 flatten in part order: flat index -> (part, rank); loads of different parts overlap
+        int part = 0;
+        for (int i = lane; i < n_peaks; i += 64) {
+            while (i >= s_off[part + 1]) part++;
+            const int r = i - s_off[part];
             const float4 p = pk_g[(size_t)part * maxp + r];
-            line_x[o + r] = (int)p.x;
-            line_y[o + r] = (int)p.y;
-            line_s[o + r] = p.z;
-            ids[part * maxp + r] = explicit_ids ? __float_as_int(p.w) : (o + r);  // :34 ids follow input order
+            line_x[i] = (int)p.x;
+            line_y[i] = (int)p.y;
+            line_s[i] = p.z;
+            ids[part * maxp + r] = explicit_ids ? __float_as_int(p.w) : i;  // :34 ids follow input order
         }
     }
     __syncthreads();
-    // every connection of the image into LDS in one sweep (independent loads, all in flight), with the
-    // (part, rank) endpoints already translated to peak ids
-    for (int limb = 0; limb < PP_NUM_LIMB; limb++) {
-        const int c = s_coff[limb + 1] - s_coff[limb], o = s_coff[limb];
-        const int part1 = d_limb_pairs[limb][0], part2 = d_limb_pairs[limb][1];
-        const float4 *cn_g = conns + ((size_t)img * PP_NUM_LIMB + limb) * maxp;
-        for (int ci = lane; ci < c; ci += 64) {
-            float4 cn = cn_g[ci];
-            cn.x = __int_as_float(ids[part1 * maxp + __float_as_int(cn.x)]);
-            cn.y = __int_as_float(ids[part2 * maxp + __float_as_int(cn.y)]);
-            s_conn[o + ci] = cn;
+    {  // every connection of the image into LDS in one flat sweep, (part, rank) end points translated to peak ids
+        const int n_conn = s_coff[PP_NUM_LIMB];
+        int limb = 0;
+        for (int i = lane; i < n_conn; i += 64) {
+            while (i >= s_coff[limb + 1]) limb++;
+            float4 cn = conns[((size_t)img * PP_NUM_LIMB + limb) * maxp + (i - s_coff[limb])];
+            cn.x = __int_as_float(ids[d_limb_pairs[limb][0] * maxp + __float_as_int(cn.x)]);
+            cn.y = __int_as_float(ids[d_limb_pairs[limb][1] * maxp + __float_as_int(cn.y)]);
+            s_conn[i] = cn;
         }
     }
     __syncthreads();
 
+    for (int i = lane; i < 4 * maxp; i += 64) s_own1[i] = 0;  // own1, own2, cb1, cb2 (contiguous); tag 0 = never valid
+    __syncthreads();
+    stamp(stamps, img, 1);
     int nskel = 0;  // uniform
     unsigned st = 0;
-    for (int limb = 0; limb < PP_NUM_LIMB; limb++) {
-        const int part1 = d_limb_pairs[limb][0], part2 = d_limb_pairs[limb][1];
-        for (int ci = s_coff[limb]; ci < s_coff[limb + 1]; ci++) {
-            const float4 cn = s_conn[ci];
-            const int id1 = __float_as_int(cn.x), id2 = __float_as_int(cn.y);
-            const float c_score = cn.z, c_len = cn.w;
-            // pl[id].score with the reference's indexing BY ID into the bucket-ordered line (:162)
-            const float ps1 = (id1 >= 0 && id1 < n_peaks) ? line_s[id1] : 0.0f;
-            const float ps2 = (id2 >= 0 && id2 < n_peaks) ? line_s[id2] : 0.0f;
-            // ---- :143-150 scan all live skeletons
-            int num_found = 0, idx1 = 0, idx2 = 0;
-            for (int base = 0; base < nskel; base += 64) {
-                const int s = base + lane;
-                bool hit = false;
-                if (s < nskel) hit = (sk_id[s * kSkelStride + part1] == id1) || (sk_id[s * kSkelStride + part2] == id2);
-                unsigned long long m = __ballot(hit);
-                if (m) {
-                    if (num_found == 0) {
-                        idx1 = base + __ffsll((long long)m) - 1;
-                        const unsigned long long m2 = m & (m - 1);
-                        if (m2) idx2 = base + __ffsll((long long)m2) - 1;
-                    } else if (num_found == 1) {
-                        idx2 = base + __ffsll((long long)m) - 1;
-                    }
-                    num_found += __popcll(m);
+    // The connections of ONE limb type have pairwise different end points, so they touch pairwise different skeletons
+    // unless (a) a skeleton holds the part-1 peak of one connection and the part-2 peak of another, (b) two skeletons
+    // hold the same peak, or (c) a connection joins two skeletons (possible merge + erase).  When none of that
+    // happens -- checked exactly, per limb -- the sequential scan of pafprocess.cpp:138-275 gives the same result in
+    // any order, and the limb's connections are applied in parallel (one lane each): owner tables peak -> skeleton
+    // replace the O(#skeletons) scan.  Otherwise the limb is processed connection by connection as the reference does.
+    auto sequential_conn = [&](int ci, int part1, int part2) -> int {  // returns the erased skeleton's index or -1
+        int erased = -1;
+        const float4 cn = s_conn[ci];
+        const int id1 = __float_as_int(cn.x), id2 = __float_as_int(cn.y);
+        const float c_score = cn.z, c_len = cn.w;
+        // pl[id].score with the reference's indexing BY ID into the bucket-ordered line (:162)
+        const float ps1 = (id1 >= 0 && id1 < n_peaks) ? line_s[id1] : 0.0f;
+        const float ps2 = (id2 >= 0 && id2 < n_peaks) ? line_s[id2] : 0.0f;
+        // ---- :143-150 scan all live skeletons
+        int num_found = 0, idx1 = 0, idx2 = 0;
+        for (int base = 0; base < nskel; base += 64) {
+            const int s = base + lane;
+            bool hit = false;
+            if (s < nskel) hit = (sk_id[s * kSkelStride + part1] == id1) || (sk_id[s * kSkelStride + part2] == id2);
+            unsigned long long m = __ballot(hit);
+            if (m) {
+                if (num_found == 0) {
+                    idx1 = base + __ffsll((long long)m) - 1;
+                    const unsigned long long m2 = m & (m - 1);
+                    if (m2) idx2 = base + __ffsll((long long)m2) - 1;
+                } else if (num_found == 1) {
+                    idx2 = base + __ffsll((long long)m) - 1;
+                }
+                num_found += __popcll(m);
+            }
+        }
+        if (num_found == 1) {  // :152-180
+            if (lane == 0) {
+                int *i1 = sk_id + idx1 * kSkelStride;
+                float *f1 = sk_sc + idx1 * kSkelStride;
+                const float len1 = f1[19];
+                const int min_len = (int)__fmul_rn(len1, 16.0f);  // :154 int truncation of length*LIMB_LENGTH_RATE
+                const int cur_id = i1[part2];
+                const float cur_sc = f1[part2];
+                if (cur_id == -1 && (float)min_len > c_len) {
+                    i1[part2] = id2;
+                    f1[part2] = c_score;
+                    i1[19] += 1;
+                    f1[19] = len1 < c_len ? c_len : len1;
+                    f1[18] = __fadd_rn(f1[18], __fadd_rn(ps2, c_score));
+                } else if ((cur_id != id2 && cur_sc <= c_score && (float)min_len > c_len) ||
+                           (cur_id == id2 && cur_sc <= c_score)) {
+                    // :163-180 the id/score are overwritten BEFORE the subtraction, so -= and += use the same
+                    // operands: total = (total - t) + t with t = pl[id2].score + conn.score
+                    i1[part2] = id2;
+                    f1[part2] = c_score;
+                    const float t = __fadd_rn(ps2, c_score);
+                    f1[18] = __fadd_rn(__fadd_rn(f1[18], -t), t);
+                    f1[19] = len1 < c_len ? c_len : len1;
                 }
             }
-            if (num_found == 1) {  // :152-180
-                if (lane == 0) {
+            __syncthreads();
+        } else if (num_found == 2) {  // :182-256, one part per lane
+            int *i1 = sk_id + idx1 * kSkelStride, *i2 = sk_id + idx2 * kSkelStride;
+            float *f1 = sk_sc + idx1 * kSkelStride, *f2 = sk_sc + idx2 * kSkelStride;
+            const bool isp = lane < PP_NUM_PART;
+            const int a_i1 = isp ? i1[lane] : -1, a_i2 = isp ? i2[lane] : -1;
+            const float a_f1 = isp ? f1[lane] : 0.0f, a_f2 = isp ? f2[lane] : 0.0f;
+            const bool a1 = a_i1 > 0, a2 = a_i2 > 0;  // :200-201 id 0 counts as unassigned
+            const bool is_member = __ballot(a1 && a2) != 0;
+            int merge = 0;
+            if (!is_member) {
+                // :203-214 running minima "min = (min == 0) ? v : min(v, min)": a plain minimum unless a value is exactly 0
+                float min1, min2;
+                if (__ballot((a1 && a_f1 == 0.0f) || (a2 && a_f2 == 0.0f))) {
+                    min1 = 0.0f;
+                    min2 = 0.0f;
+                    for (int kp = 0; kp < PP_NUM_PART; kp++) {
+                        if (i1[kp] > 0) min1 = (min1 == 0.0f) ? f1[kp] : (f1[kp] < min1 ? f1[kp] : min1);
+                        if (i2[kp] > 0) min2 = (min2 == 0.0f) ? f2[kp] : (f2[kp] < min2 ? f2[kp] : min2);
+                    }
+                } else {
+                    const float inf = __int_as_float(0x7f800000);
+                    min1 = a1 ? a_f1 : inf;
+                    min2 = a2 ? a_f2 : inf;
+#pragma unroll
+                    for (int d = 16; d >= 1; d >>= 1) {
+                        min1 = fminf(min1, __shfl_xor(min1, d));
+                        min2 = fminf(min2, __shfl_xor(min2, d));
+                    }
+                    min1 = __shfl(min1, 0);
+                    min2 = __shfl(min2, 0);
+                    if (min1 == inf) min1 = 0.0f;
+                    if (min2 == inf) min2 = 0.0f;
+                }
+                const float len1 = f1[19];
+                const int min_len = (int)__fmul_rn(len1, 16.0f);
+                const float lim = __fmul_rn((min2 < min1 ? min2 : min1), 0.7f);  // :220
+                if (c_score >= lim || c_len < (float)min_len) {                   // :221 OR
+                    // a column where BOTH rows hold an id gets their sum + 1: an id no lookup table knows (see below)
+                    const bool odd = __ballot((lane == part1 || lane == part2) && a_i1 >= 0 && a_i2 >= 0) != 0;
+                    merge = odd ? 3 : 1;
+                    const float tot = __fadd_rn(f1[18], __fadd_rn(f2[18], c_score));
+                    const int cnt = i1[19] + i2[19];
+                    if (isp) {
+                        i1[lane] = a_i1 + (a_i2 + 1);
+                        f1[lane] = __fadd_rn(a_f1, __fadd_rn(a_f2, 1.0f));
+                    }
+                    if (lane == 0) {
+                        i1[19] = cnt;
+                        f1[19] = len1 < c_len ? c_len : len1;
+                        f1[18] = tot;
+                    }
+                }
+            }
+            __syncthreads();
+            if (merge) {  // skeletons.erase(begin + idx2) (:228): every later row moves down one slot, 64 words per
+                          // step: all lanes read one row ahead, barrier, all lanes write (uniform trip count)
+                const int end = (nskel - 1) * kSkelStride;
+                for (int base = idx2 * kSkelStride; base < end; base += 64) {
+                    const int i = base + lane;
+                    const bool ok = i < end;
+                    const int v = ok ? sk_id[i + kSkelStride] : 0;
+                    const float w = ok ? sk_sc[i + kSkelStride] : 0.0f;
+                    __syncthreads();
+                    if (ok) {
+                        sk_id[i] = v;
+                        sk_sc[i] = w;
+                    }
+                    __syncthreads();
+                }
+                nskel--;
+                erased = idx2 | ((merge & 2) << 15);
+            }
+            __syncthreads();
+        } else if (num_found == 0) {  // :257-273
+            if (nskel < kMaxSkel) {
+                if (lane < 20) {
+                    int idv = -1;
+                    float scv = -1.0f;
+                    if (lane == part1) { idv = id1; scv = c_score; }
+                    if (lane == part2) { idv = id2; scv = c_score; }
+                    if (lane == 19) { idv = 2; scv = c_len; }
+                    if (lane == 18) scv = __fadd_rn(__fadd_rn(ps1, ps2), c_score);
+                    sk_id[nskel * kSkelStride + lane] = idv;
+                    sk_sc[nskel * kSkelStride + lane] = scv;
+                }
+                nskel++;
+            } else {
+                st |= PP_ST_SKEL_OVERFLOW;
+            }
+            __syncthreads();
+        }
+        // num_found > 2: no action
+        return erased;
+    };
+    for (int limb = 0; limb < PP_NUM_LIMB; limb++) {
+        const int part1 = d_limb_pairs[limb][0], part2 = d_limb_pairs[limb][1];
+        const int c0 = s_coff[limb], m = s_coff[limb + 1] - c0;
+        if (m == 0) continue;
+        if (explicit_ids || m > 64 || nskel + m > kMaxSkel) {  // plain reference order
+            for (int ci = c0; ci < c0 + m; ci++) sequential_conn(ci, part1, part2);
+            continue;
+        }
+        const int off1 = s_off[part1], off2 = s_off[part2], cnt1 = s_cnt[part1], cnt2 = s_cnt[part2];
+        // table entries carry the limb as a tag (tables zeroed once per launch), so nothing is re-initialised per limb
+        const int tag = (limb + 1) << 8;
+        int id1 = 0, id2 = 0;
+        float c_score = 0.0f, c_len = 0.0f;
+        if (lane < m) {
+            const float4 cn = s_conn[c0 + lane];
+            id1 = __float_as_int(cn.x);
+            id2 = __float_as_int(cn.y);
+            c_score = cn.z;
+            c_len = cn.w;
+            s_cb1[id1 - off1] = tag | lane;  // end points are distinct within a limb: no write conflicts
+            s_cb2[id2 - off2] = tag | lane;
+        }
+        s_conf[lane] = 0;
+        for (int sb = 0; sb < nskel; sb += 64) {  // owner tables: which skeleton holds peak r at part 1 / part 2
+            const int sidx = sb + lane;
+            if (sidx < nskel) {
+                const int r1 = sk_id[sidx * kSkelStride + part1] - off1, r2 = sk_id[sidx * kSkelStride + part2] - off2;
+                if (r1 >= 0 && r1 < cnt1) s_own1[r1] = tag | sidx;
+                if (r2 >= 0 && r2 < cnt2) s_own2[r2] = tag | sidx;
+            }
+        }
+        __syncthreads();
+        for (int sb = 0; sb < nskel; sb += 64) {  // skeleton lanes flag the connections that are not alone on a skeleton
+            const int sidx = sb + lane;
+            if (sidx < nskel) {
+                const int r1 = sk_id[sidx * kSkelStride + part1] - off1, r2 = sk_id[sidx * kSkelStride + part2] - off2;
+                int k1 = -1, k2 = -1;
+                bool multi1 = false, multi2 = false;
+                if (r1 >= 0 && r1 < cnt1) {
+                    multi1 = s_own1[r1] != (tag | sidx);  // (b): another skeleton wrote the same entry
+                    const int v = s_cb1[r1];
+                    if ((v & ~0xff) == tag) k1 = v & 0xff;
+                }
+                if (r2 >= 0 && r2 < cnt2) {
+                    multi2 = s_own2[r2] != (tag | sidx);
+                    const int v = s_cb2[r2];
+                    if ((v & ~0xff) == tag) k2 = v & 0xff;
+                }
+                const bool two = k1 >= 0 && k2 >= 0 && k1 != k2;  // (a): one skeleton, two different connections
+                if (k1 >= 0 && (multi1 || two)) s_conf[k1] = 1;
+                if (k2 >= 0 && (multi2 || two)) s_conf[k2] = 1;
+            }
+        }
+        __syncthreads();
+        int idx1 = -1;
+        bool conflict = false;
+        if (lane < m) {
+            int o1 = s_own1[id1 - off1], o2 = s_own2[id2 - off2];
+            o1 = (o1 & ~0xff) == tag ? (o1 & 0xff) : -1;
+            o2 = (o2 & ~0xff) == tag ? (o2 & 0xff) : -1;
+            conflict = s_conf[lane] != 0 || (o1 >= 0 && o2 >= 0 && o1 != o2);  // (c) two skeletons: possible merge
+            idx1 = o1 >= 0 ? o1 : o2;
+        }
+        unsigned long long confm = __ballot(conflict);
+        const float ps1 = (lane < m && id1 >= 0 && id1 < n_peaks) ? line_s[id1] : 0.0f;
+        const float ps2 = (lane < m && id2 >= 0 && id2 < n_peaks) ? line_s[id2] : 0.0f;
+        // ---- connections in order: maximal runs of independent ones in one step each, the others one by one
+        int pos = 0;
+        while (pos < m) {
+            const unsigned long long rest = confm >> pos;
+            int next = rest ? pos + __ffsll((long long)rest) - 1 : m;
+            next = next < m ? next : m;
+            if (next > pos) {
+                const bool mine = lane >= pos && lane < next;
+                const bool is_new = mine && idx1 < 0;
+                const unsigned long long mnew = __ballot(is_new);
+                if (mine && idx1 >= 0) {  // :152-180 on a skeleton no other connection of this limb touches
                     int *i1 = sk_id + idx1 * kSkelStride;
                     float *f1 = sk_sc + idx1 * kSkelStride;
                     const float len1 = f1[19];
-                    const int min_len = (int)__fmul_rn(len1, 16.0f);  // :154 int truncation of length*LIMB_LENGTH_RATE
+                    const int min_len = (int)__fmul_rn(len1, 16.0f);
                     const int cur_id = i1[part2];
                     const float cur_sc = f1[part2];
                     if (cur_id == -1 && (float)min_len > c_len) {
@@ -1228,76 +1444,54 @@ __global__ __launch_bounds__(64) void k_assemble(int maxp, int explicit_ids, con
                         f1[18] = __fadd_rn(f1[18], __fadd_rn(ps2, c_score));
                     } else if ((cur_id != id2 && cur_sc <= c_score && (float)min_len > c_len) ||
                                (cur_id == id2 && cur_sc <= c_score)) {
-                        // :163-180 the id/score are overwritten BEFORE the subtraction, so -= and += use the same
-                        // operands: total = (total - t) + t with t = pl[id2].score + conn.score
                         i1[part2] = id2;
                         f1[part2] = c_score;
                         const float t = __fadd_rn(ps2, c_score);
                         f1[18] = __fadd_rn(__fadd_rn(f1[18], -t), t);
                         f1[19] = len1 < c_len ? c_len : len1;
                     }
-                }
-                __syncthreads();
-            } else if (num_found == 2) {  // :182-256
-                if (lane == 0) {
-                    int *i1 = sk_id + idx1 * kSkelStride, *i2 = sk_id + idx2 * kSkelStride;
-                    float *f1 = sk_sc + idx1 * kSkelStride, *f2 = sk_sc + idx2 * kSkelStride;
-                    const int min_len = (int)__fmul_rn(f1[19], 16.0f);
-                    bool is_member = false;
-                    float min1 = 0.0f, min2 = 0.0f;
-                    for (int kp = 0; kp < PP_NUM_PART; kp++) {
-                        const bool a1 = i1[kp] > 0, a2 = i2[kp] > 0;  // :200-201 id 0 counts as unassigned
-                        if (a1) min1 = (min1 == 0.0f) ? f1[kp] : (f1[kp] < min1 ? f1[kp] : min1);
-                        if (a2) min2 = (min2 == 0.0f) ? f2[kp] : (f2[kp] < min2 ? f2[kp] : min2);
-                        if (a1 && a2) is_member = true;
+                } else if (is_new) {  // :257-273 new skeleton; slots in connection order
+                    const int slot = nskel + __popcll(mnew & lanemask_lt());
+                    int *i1 = sk_id + slot * kSkelStride;
+                    float *f1 = sk_sc + slot * kSkelStride;
+#pragma unroll
+                    for (int k = 0; k < 20; k++) {
+                        i1[k] = -1;
+                        f1[k] = -1.0f;
                     }
-                    int merge = 0;
-                    if (!is_member) {
-                        const float lim = __fmul_rn((min2 < min1 ? min2 : min1), 0.7f);  // :220
-                        if (c_score >= lim || c_len < (float)min_len) {                   // :221 OR
-                            for (int kp = 0; kp < PP_NUM_PART; kp++) {
-                                i1[kp] += (i2[kp] + 1);
-                                f1[kp] = __fadd_rn(f1[kp], __fadd_rn(f2[kp], 1.0f));
-                            }
-                            i1[19] += i2[19];
-                            f1[19] = f1[19] < c_len ? c_len : f1[19];
-                            f1[18] = __fadd_rn(f1[18], __fadd_rn(f2[18], c_score));
-                            merge = 1;
-                        }
-                    }
-                    s_merge = merge;
+                    i1[part1] = id1;
+                    f1[part1] = c_score;
+                    i1[part2] = id2;
+                    f1[part2] = c_score;
+                    i1[19] = 2;
+                    f1[19] = c_len;
+                    f1[18] = __fadd_rn(__fadd_rn(ps1, ps2), c_score);
                 }
-                __syncthreads();
-                if (s_merge) {  // skeletons.erase(begin + idx2): shift the tail down one slot (:228)
-                    for (int s = idx2; s < nskel - 1; s++) {
-                        if (lane < 20) {
-                            sk_id[s * kSkelStride + lane] = sk_id[(s + 1) * kSkelStride + lane];
-                            sk_sc[s * kSkelStride + lane] = sk_sc[(s + 1) * kSkelStride + lane];
-                        }
-                    }
-                    nskel--;
-                }
-                __syncthreads();
-            } else if (num_found == 0) {  // :257-273
-                if (nskel < kMaxSkel) {
-                    if (lane < 20) {
-                        int idv = -1;
-                        float scv = -1.0f;
-                        if (lane == part1) { idv = id1; scv = c_score; }
-                        if (lane == part2) { idv = id2; scv = c_score; }
-                        if (lane == 19) { idv = 2; scv = c_len; }
-                        if (lane == 18) scv = __fadd_rn(__fadd_rn(ps1, ps2), c_score);
-                        sk_id[nskel * kSkelStride + lane] = idv;
-                        sk_sc[nskel * kSkelStride + lane] = scv;
-                    }
-                    nskel++;
-                } else {
-                    st |= PP_ST_SKEL_OVERFLOW;
-                }
+                nskel += __popcll(mnew);
                 __syncthreads();
             }
-            // num_found > 2: no action
+            if (next < m) {
+                const long long t0 = stamps ? (long long)clock64() : 0;
+                const int erased = sequential_conn(c0 + next, part1, part2);
+                if (erased >= 0) {
+                    if (idx1 > (erased & 0xffff)) idx1--;  // skeletons.erase shifted every later skeleton down one slot
+                    // a merge that ADDS two real ids in the part-1/part-2 column makes an id no table knows: from
+                    // here on every connection of this limb scans the skeletons as the reference does
+                    if (erased >> 16) confm |= ~0ull << next;
+                }
+                if (stamps) {
+                    seq_cycles += (long long)clock64() - t0;
+                    seq_limbs++;
+                }
+            }
+            pos = next + 1;
         }
+    }
+    __syncthreads();
+    stamp(stamps, img, 2);
+    if (stamps && lane == 0) {
+        stamps[(size_t)img * 8 + 4] = seq_limbs;
+        stamps[(size_t)img * 8 + 5] = seq_cycles;
     }
 
     // ---- prune (:278-282) + records; order of survivors preserved
@@ -1341,6 +1535,7 @@ __global__ __launch_bounds__(64) void k_assemble(int maxp, int explicit_ids, con
         rec->n_connections = s_coff[PP_NUM_LIMB];
         rec->status = status[img] | st;
     }
+    stamp(stamps, img, 3);
 }
 
 // ================================================================================================ A8: Python twins

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-phase shader-clock breakdown of K_A / K_B (diagnostic stamps); GPU only."""
+"""Per-phase shader-clock breakdown of K_A / K_B / K_C (diagnostic stamps); GPU only."""
 import ctypes as C
 import os
 import sys
@@ -19,7 +19,8 @@ for P in (2, 6, 15, 30):
     nets = np.stack([synth.make_net_output(P, 500 + i, dtype=np.float16) for i in range(16)])
     dev = torch.from_numpy(np.concatenate([nets] * (B // 16))).cuda()
     post.process(dev, 512)
-    for name, nwg, labels in (("K_A", 18 * B, ["load", "nms", "refine"]), ("K_B", 30 * B, ["load", "score", "rank/sort", "greedy", "output"])):
+    for name, nwg, labels in (("K_A", 18 * B, ["load", "nms", "refine"]), ("K_B", 30 * B, ["load", "score", "rank/sort", "greedy", "output"]),
+                               ("K_C", B, ["load", "limbs", "records"])):
         st = torch.zeros(nwg * 8, dtype=torch.int64, device="cuda")
         L.pp_debug_set_stamps(C.c_void_p(st.data_ptr()))
         if name == "K_A":
@@ -31,8 +32,11 @@ for P in (2, 6, 15, 30):
         s = st.cpu().numpy().reshape(nwg, 8)
         ok = s[:, 0] > 0
         s = s[ok]
+        raw = s
         d = np.diff(s[:, :len(labels) + 1], axis=1)
         span = (s[:, len(labels)].max() - s[:, 0].min())
+        if name == "K_C":
+            print(f"P={P:2d} K_C: sequential limbs/img mean {raw[:, 4].mean():5.1f} max {raw[:, 4].max():3d}; cycles in them mean {raw[:, 5].mean()/1e3:6.1f} kcyc")
         print(f"P={P:2d} {name}: wgs {ok.sum():5d}  kernel span {span/1e3:8.1f} kcyc | " +
               "  ".join(f"{lab} mean {d[:, i].mean()/1e3:6.1f} max {d[:, i].max()/1e3:6.1f}" for i, lab in enumerate(labels)) +
               f" | wg total mean {(s[:, len(labels)] - s[:, 0]).mean()/1e3:6.1f} max {(s[:, len(labels)] - s[:, 0]).max()/1e3:6.1f} kcyc")
