@@ -1142,7 +1142,7 @@ __global__ __launch_bounds__(64) void k_assemble(int maxp, int explicit_ids, con
     const int *cnt_g = counts + img * PP_NUM_PART;
     const float4 *pk_g = peaks + (size_t)img * PP_NUM_PART * maxp;
     long long *stamps = d_stamps;
-    long long seq_cycles = 0, seq_limbs = 0;
+    long long seq_cycles = 0, seq_limbs = 0, odd_merges = 0;
     stamp(stamps, img, 0);
     {  // bucket offsets: one count per lane, wave prefix sums (no serial chain of global loads)
         int c = lane < PP_NUM_PART ? cnt_g[lane] : 0;
@@ -1477,7 +1477,10 @@ __global__ __launch_bounds__(64) void k_assemble(int maxp, int explicit_ids, con
                     if (idx1 > (erased & 0xffff)) idx1--;  // skeletons.erase shifted every later skeleton down one slot
                     // a merge that ADDS two real ids in the part-1/part-2 column makes an id no table knows: from
                     // here on every connection of this limb scans the skeletons as the reference does
-                    if (erased >> 16) confm |= ~0ull << next;
+                    if (erased >> 16) {
+                        confm |= ~0ull << next;
+                        odd_merges++;
+                    }
                 }
                 if (stamps) {
                     seq_cycles += (long long)clock64() - t0;
@@ -1492,6 +1495,7 @@ __global__ __launch_bounds__(64) void k_assemble(int maxp, int explicit_ids, con
     if (stamps && lane == 0) {
         stamps[(size_t)img * 8 + 4] = seq_limbs;
         stamps[(size_t)img * 8 + 5] = seq_cycles;
+        stamps[(size_t)img * 8 + 6] = odd_merges;
     }
 
     // ---- prune (:278-282) + records; order of survivors preserved

@@ -162,3 +162,25 @@ def make_scene_at_scales(n_people: int, seed: int, sizes, noise: float = 0.02, d
             out = out + rng.normal(0.0, noise, size=out.shape).astype(np.float32)
         outs.append(np.ascontiguousarray(out.astype(dtype)))
     return outs, joints
+
+
+def make_id_sum_merge_scene(weak: float = 0.8) -> np.ndarray:
+    """A hand-built (1, 50, 128, 128) float32 output (flip off) that drives pafprocess.cpp's merge (:222-228) into
+    ADDING two real peak ids: skeleton {neck 3, nose 1, Rsho 4} absorbs skeleton {nose 0, Reye 6} through the
+    connection nose 0 - Rsho 4 of limb (0, 2); `id > 0` membership (:200-201) does not see nose id 0, so the nose column
+    becomes 1 + 0 + 1 = 2 -- the id of the third nose.  The weaker connection nose 2 - Rsho 5 that follows in the same limb
+    then matches the merged skeleton and is dropped instead of founding a person: the reference reports ONE person with
+    nose id 2.  Each "person" rendered here is just the two end points of one wanted connection."""
+    def two(parts):
+        j = np.zeros((sk.NUM_PART, 3))
+        j[:, 2] = 2
+        for p, (x, y) in parts.items():
+            j[p] = (x, y, 1)
+        return j
+    n0, n1, n2 = (80, 80), (240, 80), (400, 80)
+    k1, b, c, e0 = (240, 160), (160, 200), (400, 200), (80, 30)
+    pieces = [two({1: k1, 0: n1}), two({0: n0, 14: e0}), two({1: k1, 2: b}), two({0: n0, 2: b}), two({0: n2, 2: c})]
+    maps = render_maps(np.stack(pieces), 128, 128)
+    limb = [i for i, pr in enumerate(map(tuple, sk.LIMB_PAIRS)) if pr == (0, 2)][0]
+    maps[limb, :, 80:] *= np.float32(weak)  # nose 2 - Rsho 5 ranks after nose 0 - Rsho 4
+    return np.ascontiguousarray(maps[None].astype(np.float32))

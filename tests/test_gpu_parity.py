@@ -122,6 +122,26 @@ def test_no_flip_and_empty_and_single_peak(torch_cuda, post, oracle):
     assert np.array_equal(jl, want)
 
 
+def test_assembly_merge_that_sums_two_peak_ids(torch_cuda, post, oracle):
+    """K_C applies independent connections of a limb from lookup tables; a merge that ADDS two ids (pafprocess.cpp:222-226
+    with the `id > 0` membership test) creates an id the tables cannot know, and the kernel must fall back to the
+    reference's scan for the rest of that limb.  The hand-built scene yields one person with nose id 2."""
+    from posepaf import synth
+    torch = torch_cuda
+    net = synth.make_id_sum_merge_scene()
+    rec = post.process(torch.from_numpy(net).cuda()[None], 512, flip=False)[0]
+    want = oracle.pipeline(net, 512, flip=False)
+    _records_vs_oracle(rec, want, "id-sum merge")
+    assert rec["n_humans"] == 1 and rec["humans"]["peak_id"][0, 0] == 2
+    # batched next to ordinary scenes (the fall-back is per image and per limb)
+    other = synth.make_net_output(9, 77, dtype=np.float32, flip=False)
+    both = np.stack([other, net, other])
+    recs = post.process(torch.from_numpy(both).cuda(), 512, flip=False)
+    _records_vs_oracle(recs[1], want, "id-sum merge, batched")
+    _records_vs_oracle(recs[0], oracle.pipeline(other, 512, flip=False), "neighbour 0")
+    _records_vs_oracle(recs[2], oracle.pipeline(other, 512, flip=False), "neighbour 2")
+
+
 def test_border_peaks_and_plateaus(torch_cuda, post, oracle):
     """peaks on every border/corner (clipped 3x5 / 3x3 patches) and equal-valued neighbours (plateaus)."""
     torch = torch_cuda

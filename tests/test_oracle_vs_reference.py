@@ -40,3 +40,20 @@ def test_min_img_size_prior_and_small_image(oracle, reference_cpp):
         a = oracle.process_paf(jl[None], up, size)
         b = reference_cpp.process_paf(jl[None], up, size)
         assert np.array_equal(a["ids"], b["ids"]) and np.array_equal(a["scores"], b["scores"])
+
+
+def test_merge_that_sums_two_peak_ids(oracle, reference_cpp):
+    """pafprocess.cpp:200-228: a skeleton holding peak id 0 is not seen as sharing that part, so a merge adds the two
+    ids (1 + 0 + 1 = 2) and a LATER connection of the same limb matches the made-up id.  One person, nose id 2."""
+    from posepaf import synth
+    net = synth.make_id_sum_merge_scene()
+    heat, paf = oracle.flip_average(net, flip=False)
+    jl, _ = oracle.heatmap_nms(heat)
+    up = oracle.upsample4_hwc(paf)
+    a = oracle.process_paf(jl[None], up, 512)
+    b = reference_cpp.process_paf(jl[None], up, 512)
+    assert np.array_equal(a["ids"], b["ids"]) and np.array_equal(a["scores"], b["scores"])
+    want = np.full(18, -1, np.int32)
+    want[[0, 1, 2, 14]] = (2, 3, 4, 6)
+    assert a["ids"].shape == (1, 18) and np.array_equal(a["ids"][0], want)
+    assert len(a["connections"][21]) == 2  # nose 0 - Rsho 4 first, then the dropped nose 2 - Rsho 5
