@@ -95,6 +95,7 @@ const char *pp_status_string(int status) {
         case PP_ERR_TOO_LARGE: return "batch or map size beyond the context's capacity / LDS";
         case PP_ERR_HIP: return "HIP runtime error (see pp_last_hip_error)";
         case PP_ERR_OVERFLOW: return "capacity exceeded (peaks per part or humans)";
+        case PP_ERR_UNSUPPORTED: return "shape not supported by this convolution tile configuration";
         default: return "unknown status";
     }
 }

@@ -1,0 +1,141 @@
+// A1 forward, fused convolution:  y = leaky(conv(x, w) + bias (+ residual)) (+ post)  in ONE kernel.
+//
+// The implicit-GEMM main loop is composable_kernel's DeviceGroupedConvFwdMultipleABD_Xdl_CShuffle (ROCm's CK headers,
+// the same XDL/MFMA kernels MIOpen dispatches to for these shapes -- see profiles/), instantiated here with this
+// project's own epilogue functor so that the folded-BN bias, the LeakyReLU, the residual add and the hourglass "up1 +"
+// add are applied to the fp32 accumulators in registers instead of in a second pass over the activation
+// (csrc/posepaf_epilogue.hip, 17 % of a step before).  One translation unit per tile configuration (-DPP_CONV_CFG=n):
+// the tile shapes are the f16 entries of CK's own instance list; which one runs for a given layer is measured at first use
+// (posepaf/fused_model.py).  Reference: models/layers_transposed.py Conv / Residual / Hourglass (Conv2d + BN + LeakyReLU).
+#include <array>
+#include <hip/hip_runtime.h>
+
+#include "ck/ck.hpp"
+#include "ck/tensor_operation/gpu/device/convolution_forward_specialization.hpp"
+#include "ck/tensor_operation/gpu/device/gemm_specialization.hpp"
+#include "ck/tensor_operation/gpu/device/impl/device_grouped_conv_fwd_multiple_abd_xdl_cshuffle.hpp"
+#include "ck/tensor_operation/gpu/device/tensor_layout.hpp"
+#include "ck/tensor_operation/gpu/element/element_wise_operation.hpp"
+
+#include "posepaf_conv.h"
+
+#ifndef PP_CONV_CFG
+#error "compile with -DPP_CONV_CFG=<0..8>"
+#endif
+
+namespace {
+using F16 = ck::half_t;
+using F32 = float;
+template <ck::index_t... Is>
+using S = ck::Sequence<Is...>;
+using namespace ck::tensor_layout::convolution;
+using PassThrough = ck::tensor_operation::element_wise::PassThrough;
+using ck::tensor_operation::device::ConvolutionForwardSpecialization;
+using ck::tensor_operation::device::GemmSpecialization;
+
+// epilogue on the fp32 accumulator c; d0 = bias[k]; d1 = residual (pre != 0) or post-add (pre == 0)
+struct BiasLeaky {
+    float slope;
+    template <typename E, typename C, typename D0>
+    __host__ __device__ void operator()(E &e, const C &c, const D0 &d0) const {
+        float v = c + ck::type_convert<float>(d0);
+        v = v > 0.f ? v : v * slope;
+        e = ck::type_convert<E>(v);
+    }
+};
+struct BiasAddLeaky {
+    float slope;
+    int pre;
+    template <typename E, typename C, typename D0, typename D1>
+    __host__ __device__ void operator()(E &e, const C &c, const D0 &d0, const D1 &d1) const {
+        float v = c + ck::type_convert<float>(d0);
+        const float x = ck::type_convert<float>(d1);
+        if (pre) v += x;
+        v = v > 0.f ? v : v * slope;
+        if (!pre) v += x;
+        e = ck::type_convert<E>(v);
+    }
+};
+
+// tile configurations: BlockSize, MPerBlock, NPerBlock, MXdlPerWave, NXdlPerWave, K0 x threads cluster, C-shuffle cluster
+#if PP_CONV_CFG == 0
+#define PP_TILE 256, 128, 256, 32, 8, 8, 32, 32, 2, 4
+#define PP_CLUSTER S<4, 64, 1>
+#define PP_CSHUF S<1, 32, 1, 8>
+#elif PP_CONV_CFG == 1
+#define PP_TILE 256, 256, 128, 32, 8, 8, 32, 32, 4, 2
+#define PP_CLUSTER S<4, 64, 1>
+#define PP_CSHUF S<1, 32, 1, 8>
+#elif PP_CONV_CFG == 2
+#define PP_TILE 256, 128, 128, 32, 8, 8, 32, 32, 2, 2
+#define PP_CLUSTER S<4, 64, 1>
+#define PP_CSHUF S<1, 32, 1, 8>
+#elif PP_CONV_CFG == 3
+#define PP_TILE 128, 128, 128, 32, 8, 8, 32, 32, 4, 2
+#define PP_CLUSTER S<4, 32, 1>
+#define PP_CSHUF S<1, 16, 1, 8>
+#elif PP_CONV_CFG == 4
+#define PP_TILE 128, 128, 64, 32, 8, 8, 32, 32, 2, 2
+#define PP_CLUSTER S<4, 32, 1>
+#define PP_CSHUF S<1, 32, 1, 4>
+#elif PP_CONV_CFG == 5
+#define PP_TILE 128, 64, 128, 32, 8, 8, 32, 32, 2, 2
+#define PP_CLUSTER S<4, 32, 1>
+#define PP_CSHUF S<1, 16, 1, 8>
+#elif PP_CONV_CFG == 6
+#define PP_TILE 64, 64, 64, 32, 8, 8, 32, 32, 2, 2
+#define PP_CLUSTER S<4, 16, 1>
+#define PP_CSHUF S<1, 16, 1, 4>
+#elif PP_CONV_CFG == 7
+#define PP_TILE 256, 128, 64, 32, 8, 8, 32, 32, 2, 1
+#define PP_CLUSTER S<4, 64, 1>
+#define PP_CSHUF S<1, 32, 1, 8>
+#elif PP_CONV_CFG == 8
+#define PP_TILE 256, 64, 128, 32, 8, 8, 32, 32, 1, 2
+#define PP_CLUSTER S<4, 64, 1>
+#define PP_CSHUF S<1, 32, 1, 8>
+#endif
+
+template <typename DsLayout, typename DsTypes, typename Epilogue>
+using Conv = ck::tensor_operation::device::DeviceGroupedConvFwdMultipleABD_Xdl_CShuffle<
+    2, NHWGC, GKYXC, DsLayout, NHWGK, F16, F16, F32, F16, DsTypes, F16, PassThrough, PassThrough, Epilogue,
+    ConvolutionForwardSpecialization::Default, GemmSpecialization::MNKPadding, 1, PP_TILE, PP_CLUSTER, S<1, 0, 2>, S<1, 0, 2>,
+    2, 8, 8, 1, PP_CLUSTER, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 1, 1, 1, PP_CSHUF, 8>;
+
+using ConvBias = Conv<ck::Tuple<G_K>, ck::Tuple<F16>, BiasLeaky>;
+using ConvBiasAdd = Conv<ck::Tuple<G_K, NHWGK>, ck::Tuple<F16, F16>, BiasAddLeaky>;
+
+int run(const PPConvArgs &a) {
+    using idx = ck::index_t;
+    const idx G = 1, N = a.N, H = a.H, W = a.W, C = a.C, K = a.K, R = a.R, Sx = a.S;
+    const idx Ho = H + 2 * a.pad - a.dil * (R - 1), Wo = W + 2 * a.pad - a.dil * (Sx - 1);
+    // lengths in (G, N, C|K, spatial...) order; strides describe the packed NHWGC / GKYXC / NHWGK tensors (G = 1)
+    const std::array<idx, 5> a_len{G, N, C, H, W}, a_str{C, H * W * C, 1, W * C, C};
+    const std::array<idx, 5> b_len{G, K, C, R, Sx}, b_str{K * R * Sx * C, R * Sx * C, 1, Sx * C, C};
+    const std::array<idx, 5> e_len{G, N, K, Ho, Wo}, e_str{K, Ho * Wo * K, 1, Wo * K, K};
+    const std::array<idx, 5> bias_str{K, 0, 1, 0, 0};
+    const std::array<idx, 2> strides{1, 1}, dil{a.dil, a.dil}, pads{a.pad, a.pad};
+    const StreamConfig cfg{static_cast<hipStream_t>(a.stream), false};
+    if (a.extra_mode == 0) {
+        ConvBias op;
+        auto arg = op.MakeArgument(a.x, a.w, std::array<const void *, 1>{a.bias}, a.y, a_len, a_str, b_len, b_str,
+                                   std::array<std::array<idx, 5>, 1>{e_len}, std::array<std::array<idx, 5>, 1>{bias_str}, e_len,
+                                   e_str, strides, dil, pads, pads, PassThrough{}, PassThrough{}, BiasLeaky{a.slope});
+        if (!op.IsSupportedArgument(arg)) return -1;
+        op.MakeInvoker().Run(arg, cfg);
+    } else {
+        ConvBiasAdd op;
+        auto arg = op.MakeArgument(a.x, a.w, std::array<const void *, 2>{a.bias, a.extra}, a.y, a_len, a_str, b_len, b_str,
+                                   std::array<std::array<idx, 5>, 2>{e_len, e_len},
+                                   std::array<std::array<idx, 5>, 2>{bias_str, e_str}, e_len, e_str, strides, dil, pads, pads,
+                                   PassThrough{}, PassThrough{}, BiasAddLeaky{a.slope, a.extra_mode == 1});
+        if (!op.IsSupportedArgument(arg)) return -1;
+        op.MakeInvoker().Run(arg, cfg);
+    }
+    return 0;
+}
+}  // namespace
+
+#define PP_CAT2(a, b) a##b
+#define PP_CAT(a, b) PP_CAT2(a, b)
+int PP_CAT(pp_conv_run_cfg, PP_CONV_CFG)(const PPConvArgs &a) { return run(a); }

@@ -22,6 +22,17 @@ LEAK = 0.01
 # 64x128x128 batch): 2.1-3.2 TB/s, i.e. 0.83-1.21x of MIOpen's CK kernel + the separate epilogue pass, which both already
 # stream near the HBM rate -- not a win yet at one 4-wave workgroup per CU, so it stays off by default.
 USE_PWCONV = False
+# Fused convolution + epilogue in one kernel (csrc/posepaf_conv_inst.hip: composable_kernel's XDL implicit-GEMM main loop with
+# this project's bias / LeakyReLU / residual / post-add functor on the fp32 accumulators).  Per layer shape the tile
+# configurations AND the MIOpen-convolution + separate-epilogue path are timed once, at first (eager) use, and the fastest is kept.
+USE_FUSED_CONV = True
+_conv_choice: dict = {}   # shape key -> tile configuration id, or -1 = MIOpen convolution + k_bias_act pass
+_TUNE_REPS = 3
+
+
+def conv_choices() -> dict:
+    """The per-shape decisions taken so far (for bench.py / DESIGN.md)."""
+    return dict(_conv_choice)
 
 
 def _cl(t):
@@ -109,8 +120,76 @@ class FConv(nn.Module):
         from . import _lib
         return bool(_lib.load().pp_pwconv_supported(self.weight.shape[1], self.weight.shape[0]))
 
+    # ---- fused convolution (pp_conv_f16)
+    def _fused_eligible(self, x, res, post):
+        return (USE_FUSED_CONV and x.is_cuda and x.dtype == torch.float16 and self.stride == (1, 1)
+                and self.weight.shape[2] == self.weight.shape[3] and self.padding[0] == self.padding[1]
+                and self.dilation[0] == self.dilation[1] and self.weight.shape[0] % 8 == 0 and self.weight.shape[1] % 8 == 0
+                and not (res is not None and post is not None))
+
+    def _fused_launch(self, cfg, x, extra, mode, y):
+        from . import _lib
+        n, c, h, w = x.shape
+        return _lib.load().pp_conv_f16(_ptr(x), _ptr(self.weight), _ptr(self.bias), _ptr(extra), _ptr(y), n, h, w, c,
+                                       self.weight.shape[0], self.weight.shape[2], self.padding[0], self.dilation[0], mode,
+                                       LEAK if self.act else 1.0, cfg, _stream(x))
+
+    def _fused(self, x, res, post):
+        """-> y, or None when this shape runs faster (or only) on the MIOpen + epilogue path."""
+        from . import _lib
+        x = _cl(x)
+        extra = res if res is not None else post
+        extra = _cl(extra) if extra is not None else None
+        mode = 1 if res is not None else (2 if post is not None else 0)
+        if not self.weight.is_contiguous(memory_format=torch.channels_last):
+            self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
+        n, c, h, w = x.shape
+        k, r = self.weight.shape[0], self.weight.shape[2]
+        ho = h + 2 * self.padding[0] - self.dilation[0] * (r - 1)
+        wo = w + 2 * self.padding[0] - self.dilation[0] * (r - 1)
+        key = (n, c, h, w, k, r, self.padding[0], self.dilation[0], mode, bool(self.act))
+        choice = _conv_choice.get(key)
+        y = torch.empty((n, k, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        if choice is None:
+            if torch.cuda.is_current_stream_capturing():
+                return None  # cannot time inside a capture; shapes are tuned by the eager warm-up pass
+            choice = self._tune(key, x, extra, mode, y, res, post)
+        if choice < 0:
+            return None
+        _lib.check(self._fused_launch(choice, x, extra, mode, y))
+        return y
+
+    def _tune(self, key, x, extra, mode, y, res, post):
+        from . import _lib
+        L = _lib.load()
+
+        def timed(fn):
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(_TUNE_REPS):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / _TUNE_REPS
+
+        best, best_t = -1, timed(lambda: hip_bias_act_(self.conv_only(x), self.bias, res, self.act, post))
+        for cfg in range(L.pp_conv_num_configs()):
+            if self._fused_launch(cfg, x, extra, mode, y) != 0:
+                continue
+            t = timed(lambda: self._fused_launch(cfg, x, extra, mode, y))
+            if t < best_t:
+                best, best_t = cfg, t
+        _conv_choice[key] = best
+        return best
+
     def forward(self, x, res=None, post=None):
         """act(conv(x) + bias (+ res)) (+ post)"""
+        if self._fused_eligible(x, res, post):
+            y = self._fused(x, res, post)
+            if y is not None:
+                return y
         if self._pointwise_ok(x):   # 1x1: one MFMA GEMM with the epilogue fused (csrc/posepaf_pwconv.hip)
             from . import _lib
             x = _cl(x)

@@ -43,7 +43,8 @@ typedef enum {
     PP_ERR_BAD_ARG = -2,
     PP_ERR_TOO_LARGE = -3,   /* batch/h/w beyond what the context was created for, or map does not fit LDS */
     PP_ERR_HIP = -4,         /* a HIP call failed; pp_last_hip_error() has the code */
-    PP_ERR_OVERFLOW = -5     /* compat path only: a per-part / per-image capacity was exceeded */
+    PP_ERR_OVERFLOW = -5,    /* compat path only: a per-part / per-image capacity was exceeded */
+    PP_ERR_UNSUPPORTED = -6  /* pp_conv_f16: this tile configuration / channel count is not available for the shape */
 } pp_status;
 
 typedef enum { PP_F32 = 0, PP_F16 = 1 } pp_dtype;
@@ -153,6 +154,22 @@ PP_API int pp_upsample2_f16(const void *x, void *y, long n, int h_in, int w_in, 
 PP_API int pp_pwconv_supported(int K, int N);
 PP_API int pp_pwconv_f16(const void *x, const void *w, const void *bias, const void *residual, const void *post, void *y,
                          long M, int K, int N, float slope, int has_act, void *stream);
+
+/* A1 forward: one fused convolution on the matrix cores, stride 1, square kernel, fp16 in/out, fp32 accumulate:
+ *   y = leaky(conv(x, w) + bias[k] (+ extra if extra_mode == 1)) (+ extra if extra_mode == 2)
+ * i.e. Conv2d + folded BatchNorm + LeakyReLU of models/layers_transposed.py:Conv, with the residual add of
+ * Residual.forward (extra_mode 1) or the hourglass's `up1 +` (extra_mode 2) applied to the fp32 accumulators.
+ * x: DEVICE (n, h, w, c_in) NHWC; w: DEVICE (c_out, ksize, ksize, c_in) (= a channels-last (c_out, c_in, k, k) weight);
+ * bias fp16[c_out]; extra: DEVICE (n, ho, wo, c_out) or NULL (extra_mode 0); y: DEVICE (n, ho, wo, c_out) with
+ * ho = h + 2*pad - dilation*(ksize-1).  slope = LeakyReLU slope (1.0f = no activation).  c_in, c_out multiples of 8,
+ * all pointers 16-byte aligned.  config in [0, pp_conv_num_configs()) picks the workgroup tile (M x N per block:
+ * 0 128x256, 1 256x128, 2 128x128, 3 128x128/128 threads, 4 128x64, 5 64x128, 6 64x64, 7 128x64/256, 8 64x128/256);
+ * callers time the configurations once per layer shape and keep the fastest (posepaf/fused_model.py).
+ * The GEMM main loop is ROCm composable_kernel's XDL implicit-GEMM template; the epilogue functor is this library's. */
+PP_API int pp_conv_num_configs(void);
+PP_API int pp_conv_f16(const void *x, const void *w, const void *bias, const void *extra, void *y, int n, int h, int wd,
+                       int c_in, int c_out, int ksize, int pad, int dilation, int extra_mode, float slope, int config,
+                       void *stream);
 
 /* A0 pre-processing (utils/parse_skeletons.py:52-73, utils/util.py:44-65) of a batch of equally sized BGR uint8 DEVICE
  * images (batch, h, w, 3): pad bottom/right to a multiple of pad_to with pad_value, divide by 255, and write each image

@@ -116,3 +116,69 @@ def test_pwconv_mfma_kernel_matches_torch(K, N):
         assert torch.isfinite(y).all()
         assert err < 2e-2, (K, N, res is not None, act, post is not None, err)
     assert L.pp_pwconv_supported(384, 192) == 0 and L.pp_pwconv_supported(256, 384) == 0 and L.pp_pwconv_supported(256, 256) == 0
+
+
+@pytest.mark.parametrize("shape", [
+    # n, c_in, c_out, h, w, ksize, pad, dilation
+    (2, 64, 64, 32, 32, 3, 1, 1),
+    (1, 128, 128, 24, 40, 3, 3, 3),     # the dilated 3x3 of the feature heads
+    (2, 256, 128, 16, 16, 1, 0, 1),
+    (1, 192, 384, 8, 8, 1, 0, 1),
+    (3, 72, 40, 9, 7, 3, 1, 1),          # ragged: nothing is a multiple of a tile
+])
+def test_fused_convolution_matches_torch(shape):
+    """pp_conv_f16 (every tile configuration that accepts the shape) against an fp32 torch convolution of the same
+    fp16 operands: bias, LeakyReLU, residual-before-activation and add-after-activation variants.  fp32 accumulate, fp16
+    store: tolerance 2e-3 relative to the output scale."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from posepaf import _lib
+    L = _lib.load()
+    n, ci, co, h, w, k, pad, dil = shape
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn(n, ci, h, w, generator=g).cuda().half().contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5).cuda().half().contiguous(memory_format=torch.channels_last)
+    b = torch.randn(co, generator=g).cuda().half()
+    ho, wo = h + 2 * pad - dil * (k - 1), w + 2 * pad - dil * (k - 1)
+    ex = torch.randn(n, co, ho, wo, generator=g).cuda().half().contiguous(memory_format=torch.channels_last)
+    conv = F.conv2d(x.float(), wt.float(), b.float(), 1, pad, dil)
+    vp = C.c_void_p
+    stream = vp(torch.cuda.current_stream().cuda_stream)
+    ran = 0
+    for mode, slope in [(0, 0.01), (1, 0.01), (2, 0.01), (0, 1.0), (1, 1.0)]:
+        ref = conv + ex.float() if mode == 1 else conv
+        ref = F.leaky_relu(ref, slope) if slope != 1.0 else ref
+        ref = ref + ex.float() if mode == 2 else ref
+        for cfg in range(L.pp_conv_num_configs()):
+            y = torch.full((n, co, ho, wo), float("nan"), dtype=torch.float16, device="cuda").contiguous(memory_format=torch.channels_last)
+            rc = L.pp_conv_f16(vp(x.data_ptr()), vp(wt.data_ptr()), vp(b.data_ptr()), vp(ex.data_ptr()) if mode else None,
+                               vp(y.data_ptr()), n, h, w, ci, co, k, pad, dil, mode, slope, cfg, stream)
+            if rc == -6:   # PP_ERR_UNSUPPORTED: this tile configuration does not take the shape
+                continue
+            assert rc == 0, (cfg, mode, rc)
+            torch.cuda.synchronize()
+            err = (y.float() - ref).abs().max().item()
+            assert err <= 2e-3 * max(1.0, ref.abs().max().item()), (shape, cfg, mode, slope, err)
+            ran += 1
+    assert ran >= 5, "no tile configuration accepted this shape"
+    # argument errors are loud
+    assert L.pp_conv_f16(vp(x.data_ptr()), vp(wt.data_ptr()), vp(b.data_ptr()), None, vp(y.data_ptr()), n, h, w, ci, co, k, pad,
+                         dil, 1, 0.01, 0, stream) == -2          # extra_mode without a tensor
+    assert L.pp_conv_f16(vp(x.data_ptr()), vp(wt.data_ptr()), vp(b.data_ptr()), None, vp(y.data_ptr()), n, h, w, ci, co, k, pad,
+                         dil, 0, 0.01, 99, stream) == -2         # unknown configuration
+
+
+def test_fused_convolution_autotune_keeps_model_output():
+    """The forward with the fused convolutions on and off (MIOpen + epilogue pass) agrees within fp16 noise."""
+    from posepaf import fused_model as fm
+    model = fm.build_inference_model(torch.device("cuda", 0))
+    x = torch.from_numpy(np.random.default_rng(4).random((2, 128, 128, 3), dtype=np.float32)).cuda().half()
+    with torch.no_grad():
+        fm.USE_FUSED_CONV = False
+        try:
+            a = model(x).float()
+        finally:
+            fm.USE_FUSED_CONV = True
+        b = model(x).float()
+    assert any(v >= 0 for v in fm.conv_choices().values()), "no layer chose a fused configuration"
+    assert (a - b).abs().max().item() <= 0.02 * a.abs().max().item()
