@@ -43,6 +43,7 @@ IMG = 512
 FEAT = IMG // 4
 SCENE_PEOPLE = (1, 2, 3, 4, 5, 6, 8, 10, 12, 15, 20, 30, 2, 4, 6, 3)   # people per synthetic scene (mean 8.2)
 HBM_PEAK_GBS = 8000.0                                                   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F16_PEAK_TFLOPS = 2500.0                                           # MI355X_MICROARCH.md: dense fp16/bf16 MFMA peak
 FLOP_PER_IMAGE = 2 * 529.4e9                                            # 529.4 GFLOP / forward, x2 flip
 
 
@@ -149,6 +150,11 @@ def bench_multiscale(a, world, rank, dev, dist, backend, model, post, images):
             "config": {"workload": "configs[4]: original path, scales {0.5,1.0,1.5} x 512 + flip, float64 accumulation at image "
                                    "resolution in HBM, find_peaks + Python-twin matching", "images_per_gpu_per_step": B,
                        "people_per_scene": list(SCENE_PEOPLE), "parallelism": f"image-sharded x{world}"},
+            "roofline_forward": None if a.postproc_only else {
+                "bound": "mfma", "achieved": B * a.steps * FLOP_PER_IMAGE / dt / 1e12, "peak": MFMA_F16_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": B * a.steps * FLOP_PER_IMAGE / dt / 1e12 / MFMA_F16_PEAK_TFLOPS,
+                "note": "whole step time (forward + pre/post-processing) against the dense fp16 MFMA peak"},
+            "conv_layers": conv_summary,
             "humans_found_in_batch": int(recs["n_humans"].sum()), "status_or": int(np.bitwise_or.reduce(recs["status"]))}), flush=True)
     if world > 1:
         dist.barrier()
@@ -268,6 +274,12 @@ def main():
         except Exception:
             traffic = None
 
+    conv_summary = None
+    if model is not None and not a.plain_model:
+        from posepaf.fused_model import conv_choices
+        ch = conv_choices()
+        conv_summary = {"shapes_fused_kernel": sum(1 for v in ch.values() if v >= 0),
+                        "shapes_miopen_plus_epilogue": sum(1 for v in ch.values() if v < 0)}
     if rank == 0:
         out = {
             "metric": "end-to-end images/sec at 512x512", "value": world * B * a.steps / dt, "unit": "images/sec",

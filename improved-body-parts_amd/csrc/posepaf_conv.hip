@@ -35,6 +35,11 @@ extern "C" int pp_conv_f16(const void *x, const void *w, const void *bias, const
         case 6: rc = pp_conv_run_cfg6(a); break;
         case 7: rc = pp_conv_run_cfg7(a); break;
         case 8: rc = pp_conv_run_cfg8(a); break;
+        case 9: rc = pp_conv_run_cfg9(a); break;
+        case 10: rc = pp_conv_run_cfg10(a); break;
+        case 11: rc = pp_conv_run_cfg11(a); break;
+        case 12: rc = pp_conv_run_cfg12(a); break;
+        case 13: rc = pp_conv_run_cfg13(a); break;
     }
     if (rc != 0) return PP_ERR_UNSUPPORTED;
     return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;

@@ -14,13 +14,14 @@
 #include "ck/tensor_operation/gpu/device/convolution_forward_specialization.hpp"
 #include "ck/tensor_operation/gpu/device/gemm_specialization.hpp"
 #include "ck/tensor_operation/gpu/device/impl/device_grouped_conv_fwd_multiple_abd_xdl_cshuffle.hpp"
+#include "ck/tensor_operation/gpu/device/impl/device_grouped_conv_fwd_multiple_abd_xdl_cshuffle_v3.hpp"
 #include "ck/tensor_operation/gpu/device/tensor_layout.hpp"
 #include "ck/tensor_operation/gpu/element/element_wise_operation.hpp"
 
 #include "posepaf_conv.h"
 
 #ifndef PP_CONV_CFG
-#error "compile with -DPP_CONV_CFG=<0..8>"
+#error "compile with -DPP_CONV_CFG=<0..13>"
 #endif
 
 namespace {
@@ -94,13 +95,57 @@ struct BiasAddLeaky {
 #define PP_TILE 256, 64, 128, 32, 8, 8, 32, 32, 1, 2
 #define PP_CLUSTER S<4, 64, 1>
 #define PP_CSHUF S<1, 32, 1, 8>
+// 9..13: the newer "V3" device op (software-pipelined block GEMM, KPerBlock 64)
+#elif PP_CONV_CFG == 9
+#define PP_V3
+#define PP_TILE 256, 128, 128, 64, 16, 16, 32, 32, 2, 2
+#define PP_CLUSTER S<4, 64, 1>
+#define PP_LDSPAD 1
+#define PP_CSHUF S<1, 32, 1, 8>
+#define PP_PIPE ck::BlockGemmPipelineScheduler::Interwave, ck::BlockGemmPipelineVersion::v1
+#elif PP_CONV_CFG == 10
+#define PP_V3
+#define PP_TILE 256, 128, 128, 64, 8, 8, 32, 32, 2, 2
+#define PP_CLUSTER S<8, 32, 1>
+#define PP_LDSPAD 0
+#define PP_CSHUF S<1, 32, 1, 8>
+#define PP_PIPE ck::BlockGemmPipelineScheduler::Intrawave, ck::BlockGemmPipelineVersion::v4
+#elif PP_CONV_CFG == 11
+#define PP_V3
+#define PP_TILE 256, 128, 128, 64, 8, 8, 32, 32, 2, 2
+#define PP_CLUSTER S<8, 32, 1>
+#define PP_LDSPAD 0
+#define PP_CSHUF S<1, 32, 1, 8>
+#define PP_PIPE ck::BlockGemmPipelineScheduler::Intrawave, ck::BlockGemmPipelineVersion::v3
+#elif PP_CONV_CFG == 12
+#define PP_V3
+#define PP_TILE 256, 256, 256, 32, 8, 8, 32, 32, 4, 4
+#define PP_CLUSTER S<4, 64, 1>
+#define PP_LDSPAD 0
+#define PP_CSHUF S<1, 32, 1, 8>
+#define PP_PIPE ck::BlockGemmPipelineScheduler::Intrawave, ck::BlockGemmPipelineVersion::v3
+#elif PP_CONV_CFG == 13
+#define PP_V3
+#define PP_TILE 256, 256, 128, 64, 16, 16, 32, 32, 4, 2
+#define PP_CLUSTER S<4, 64, 1>
+#define PP_LDSPAD 1
+#define PP_CSHUF S<1, 32, 1, 8>
+#define PP_PIPE ck::BlockGemmPipelineScheduler::Interwave, ck::BlockGemmPipelineVersion::v1
 #endif
 
+#ifdef PP_V3
+template <typename DsLayout, typename DsTypes, typename Epilogue>
+using Conv = ck::tensor_operation::device::DeviceGroupedConvFwdMultipleABD_Xdl_CShuffle_V3<
+    2, NHWGC, GKYXC, DsLayout, NHWGK, F16, F16, F32, F16, DsTypes, F16, PassThrough, PassThrough, Epilogue,
+    ConvolutionForwardSpecialization::Default, GemmSpecialization::MNKPadding, PP_TILE, PP_CLUSTER, S<1, 0, 2>, S<1, 0, 2>, 2, 8,
+    8, PP_LDSPAD, PP_CLUSTER, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, PP_LDSPAD, 1, 1, PP_CSHUF, 8, PP_PIPE>;
+#else
 template <typename DsLayout, typename DsTypes, typename Epilogue>
 using Conv = ck::tensor_operation::device::DeviceGroupedConvFwdMultipleABD_Xdl_CShuffle<
     2, NHWGC, GKYXC, DsLayout, NHWGK, F16, F16, F32, F16, DsTypes, F16, PassThrough, PassThrough, Epilogue,
     ConvolutionForwardSpecialization::Default, GemmSpecialization::MNKPadding, 1, PP_TILE, PP_CLUSTER, S<1, 0, 2>, S<1, 0, 2>,
     2, 8, 8, 1, PP_CLUSTER, S<1, 0, 2>, S<1, 0, 2>, 2, 8, 8, 1, 1, 1, PP_CSHUF, 8>;
+#endif
 
 using ConvBias = Conv<ck::Tuple<G_K>, ck::Tuple<F16>, BiasLeaky>;
 using ConvBiasAdd = Conv<ck::Tuple<G_K, NHWGK>, ck::Tuple<F16, F16>, BiasAddLeaky>;

@@ -27,6 +27,8 @@ USE_PWCONV = False
 # configurations AND the MIOpen-convolution + separate-epilogue path are timed once, at first (eager) use, and the fastest is kept.
 USE_FUSED_CONV = True
 _conv_choice: dict = {}   # shape key -> tile configuration id, or -1 = MIOpen convolution + k_bias_act pass
+_conv_timing: dict = {}   # shape key -> {"miopen": ms, cfg: ms, ...} measured by the autotune (diagnostics)
+_conv_calls: dict = {}    # shape key -> number of forward() calls since import (diagnostics)
 _TUNE_REPS = 3
 
 
@@ -149,6 +151,7 @@ class FConv(nn.Module):
         wo = w + 2 * self.padding[0] - self.dilation[0] * (r - 1)
         key = (n, c, h, w, k, r, self.padding[0], self.dilation[0], mode, bool(self.act))
         choice = _conv_choice.get(key)
+        _conv_calls[key] = _conv_calls.get(key, 0) + 1
         y = torch.empty((n, k, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         if choice is None:
             if torch.cuda.is_current_stream_capturing():
@@ -175,13 +178,16 @@ class FConv(nn.Module):
             return e0.elapsed_time(e1) / _TUNE_REPS
 
         best, best_t = -1, timed(lambda: hip_bias_act_(self.conv_only(x), self.bias, res, self.act, post))
+        times = {"miopen": best_t}
         for cfg in range(L.pp_conv_num_configs()):
             if self._fused_launch(cfg, x, extra, mode, y) != 0:
                 continue
             t = timed(lambda: self._fused_launch(cfg, x, extra, mode, y))
+            times[cfg] = t
             if t < best_t:
                 best, best_t = cfg, t
         _conv_choice[key] = best
+        _conv_timing[key] = times
         return best
 
     def forward(self, x, res=None, post=None):

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Per-layer-shape table of the forward's convolutions at the bench batch (64 x 512 x 512): calls per forward, chosen tile
+configuration, its time, the MIOpen + epilogue time, TFLOP/s and the minimum-traffic GB/s.  GPU only."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "improved-body-parts_amd")):
+    sys.path.insert(0, p)
+import torch
+from posepaf import fused_model as fm
+
+torch.backends.cudnn.benchmark = True
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+model = fm.build_inference_model(torch.device("cuda", 0))
+x = torch.rand(B, 512, 512, 3, device="cuda").half()
+with torch.no_grad():
+    model(x)
+    fm._conv_calls.clear()
+    model(x)
+torch.cuda.synchronize()
+rows = []
+for key, times in fm._conv_timing.items():
+    n, c, h, w, k, r, pad, dil, mode, act = key
+    calls = fm._conv_calls.get(key, 0)
+    best = fm._conv_choice[key]
+    t = times["miopen"] if best < 0 else times[best]
+    flop = 2.0 * n * h * w * c * k * r * r
+    byts = 2.0 * n * h * w * (c + k * (2 if mode else 1)) + 2.0 * k * c * r * r
+    rows.append((calls * t, key, calls, best, t, times["miopen"], flop / t / 1e9, byts / t / 1e6))
+rows.sort(reverse=True)
+tot = sum(r[0] for r in rows)
+print(f"{'c_in':>5} {'c_out':>5} {'hxw':>9} k pad dil mode act | calls cfg   best_ms  miopen_ms  TFLOP/s    GB/s  share")
+for tt, key, calls, best, t, tm, tf, gb in rows:
+    n, c, h, w, k, r, pad, dil, mode, act = key
+    print(f"{c:5d} {k:5d} {h:4d}x{w:<4d} {r} {pad:3d} {dil:3d} {mode:4d} {int(act):3d} | {calls:5d} {best:3d} {t:9.3f} {tm:10.3f} {tf:8.0f} {gb:7.0f} {100 * tt / tot:5.1f}%")
+print(f"sum over tuned shapes: {tot:.2f} ms per forward")
