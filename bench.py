@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("POSEPAF_BENCH_BATCH", "32")),
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("POSEPAF_BENCH_BATCH", "64")),
                     help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="bound on the CPU baseline leg")
@@ -150,11 +150,6 @@ def bench_multiscale(a, world, rank, dev, dist, backend, model, post, images):
             "config": {"workload": "configs[4]: original path, scales {0.5,1.0,1.5} x 512 + flip, float64 accumulation at image "
                                    "resolution in HBM, find_peaks + Python-twin matching", "images_per_gpu_per_step": B,
                        "people_per_scene": list(SCENE_PEOPLE), "parallelism": f"image-sharded x{world}"},
-            "roofline_forward": None if a.postproc_only else {
-                "bound": "mfma", "achieved": B * a.steps * FLOP_PER_IMAGE / dt / 1e12, "peak": MFMA_F16_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": B * a.steps * FLOP_PER_IMAGE / dt / 1e12 / MFMA_F16_PEAK_TFLOPS,
-                "note": "whole step time (forward + pre/post-processing) against the dense fp16 MFMA peak"},
-            "conv_layers": conv_summary,
             "humans_found_in_batch": int(recs["n_humans"].sum()), "status_or": int(np.bitwise_or.reduce(recs["status"]))}), flush=True)
     if world > 1:
         dist.barrier()
@@ -292,6 +287,11 @@ def main():
                                    "configs[2] post-processing only", "images_per_gpu_per_step": B,
                        "people_per_scene": list(SCENE_PEOPLE), "parallelism": f"image-sharded x{world}"},
             "forward_tflops_per_gpu": None if a.postproc_only else B * a.steps * FLOP_PER_IMAGE / dt / 1e12,
+            "roofline_forward": None if a.postproc_only else {
+                "bound": "mfma", "achieved": B * a.steps * FLOP_PER_IMAGE / dt / 1e12, "peak": MFMA_F16_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": B * a.steps * FLOP_PER_IMAGE / dt / 1e12 / MFMA_F16_PEAK_TFLOPS,
+                "note": "whole step time (forward + pre/post-processing) against the dense fp16 MFMA peak"},
+            "conv_layers": conv_summary,
             "humans_found_in_batch": int(recs["n_humans"].sum()), "status_or": int(np.bitwise_or.reduce(recs["status"])),
             "kernel_ms": ms,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
