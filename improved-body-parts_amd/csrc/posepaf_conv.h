@@ -8,9 +8,9 @@ struct PPConvArgs {
     float slope;                       // LeakyReLU slope; 1.0 = no activation
     void *stream;
 };
-constexpr int kNumConvConfigs = 14;
+constexpr int kNumConvConfigs = 10;
 // returns 0 ok, -1 shape not supported by this tile configuration
 #define PP_CONV_DECL(n) int pp_conv_run_cfg##n(const PPConvArgs &a);
 PP_CONV_DECL(0) PP_CONV_DECL(1) PP_CONV_DECL(2) PP_CONV_DECL(3) PP_CONV_DECL(4) PP_CONV_DECL(5) PP_CONV_DECL(6) PP_CONV_DECL(7)
-PP_CONV_DECL(8) PP_CONV_DECL(9) PP_CONV_DECL(10) PP_CONV_DECL(11) PP_CONV_DECL(12) PP_CONV_DECL(13)
+PP_CONV_DECL(8) PP_CONV_DECL(9)
 #undef PP_CONV_DECL

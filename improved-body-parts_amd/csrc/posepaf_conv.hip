@@ -21,8 +21,8 @@ extern "C" int pp_conv_f16(const void *x, const void *w, const void *bias, const
     if (al & 15) return PP_ERR_BAD_ARG;
     const long ho = (long)h + 2L * pad - (long)dilation * (ksize - 1), wo = (long)wd + 2L * pad - (long)dilation * (ksize - 1);
     if (ho <= 0 || wo <= 0) return PP_ERR_BAD_ARG;
-    // 32-bit element offsets inside the kernels
-    if ((long)n * h * wd * c_in >= (1L << 31) || (long)n * ho * wo * c_out >= (1L << 31)) return PP_ERR_TOO_LARGE;
+    // 32-bit byte offsets inside the kernels: each tensor at most 2 GB
+    if ((long)n * h * wd * c_in * 2 > (1L << 31) || (long)n * ho * wo * c_out * 2 > (1L << 31)) return PP_ERR_TOO_LARGE;
     const PPConvArgs a{x, w, bias, extra, y, n, h, wd, c_in, c_out, ksize, ksize, pad, dilation, extra_mode, slope, stream};
     int rc = -1;
     switch (config) {
@@ -36,10 +36,6 @@ extern "C" int pp_conv_f16(const void *x, const void *w, const void *bias, const
         case 7: rc = pp_conv_run_cfg7(a); break;
         case 8: rc = pp_conv_run_cfg8(a); break;
         case 9: rc = pp_conv_run_cfg9(a); break;
-        case 10: rc = pp_conv_run_cfg10(a); break;
-        case 11: rc = pp_conv_run_cfg11(a); break;
-        case 12: rc = pp_conv_run_cfg12(a); break;
-        case 13: rc = pp_conv_run_cfg13(a); break;
     }
     if (rc != 0) return PP_ERR_UNSUPPORTED;
     return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;

@@ -21,7 +21,7 @@
 #include "posepaf_conv.h"
 
 #ifndef PP_CONV_CFG
-#error "compile with -DPP_CONV_CFG=<0..13>"
+#error "compile with -DPP_CONV_CFG=<0..9>"
 #endif
 
 namespace {
@@ -72,65 +72,46 @@ struct BiasAddLeaky {
 #define PP_CLUSTER S<4, 64, 1>
 #define PP_CSHUF S<1, 32, 1, 8>
 #elif PP_CONV_CFG == 3
-#define PP_TILE 128, 128, 128, 32, 8, 8, 32, 32, 4, 2
-#define PP_CLUSTER S<4, 32, 1>
-#define PP_CSHUF S<1, 16, 1, 8>
-#elif PP_CONV_CFG == 4
 #define PP_TILE 128, 128, 64, 32, 8, 8, 32, 32, 2, 2
 #define PP_CLUSTER S<4, 32, 1>
 #define PP_CSHUF S<1, 32, 1, 4>
-#elif PP_CONV_CFG == 5
-#define PP_TILE 128, 64, 128, 32, 8, 8, 32, 32, 2, 2
-#define PP_CLUSTER S<4, 32, 1>
-#define PP_CSHUF S<1, 16, 1, 8>
-#elif PP_CONV_CFG == 6
-#define PP_TILE 64, 64, 64, 32, 8, 8, 32, 32, 2, 2
-#define PP_CLUSTER S<4, 16, 1>
-#define PP_CSHUF S<1, 16, 1, 4>
-#elif PP_CONV_CFG == 7
+#elif PP_CONV_CFG == 4
 #define PP_TILE 256, 128, 64, 32, 8, 8, 32, 32, 2, 1
 #define PP_CLUSTER S<4, 64, 1>
 #define PP_CSHUF S<1, 32, 1, 8>
-#elif PP_CONV_CFG == 8
+#elif PP_CONV_CFG == 5
 #define PP_TILE 256, 64, 128, 32, 8, 8, 32, 32, 1, 2
 #define PP_CLUSTER S<4, 64, 1>
 #define PP_CSHUF S<1, 32, 1, 8>
-// 9..13: the newer "V3" device op (software-pipelined block GEMM, KPerBlock 64)
-#elif PP_CONV_CFG == 9
-#define PP_V3
-#define PP_TILE 256, 128, 128, 64, 16, 16, 32, 32, 2, 2
-#define PP_CLUSTER S<4, 64, 1>
-#define PP_LDSPAD 1
-#define PP_CSHUF S<1, 32, 1, 8>
-#define PP_PIPE ck::BlockGemmPipelineScheduler::Interwave, ck::BlockGemmPipelineVersion::v1
-#elif PP_CONV_CFG == 10
+#elif PP_CONV_CFG == 6
+// 6..9: the newer "V3" device op (software-pipelined block GEMM)
 #define PP_V3
 #define PP_TILE 256, 128, 128, 64, 8, 8, 32, 32, 2, 2
 #define PP_CLUSTER S<8, 32, 1>
 #define PP_LDSPAD 0
 #define PP_CSHUF S<1, 32, 1, 8>
 #define PP_PIPE ck::BlockGemmPipelineScheduler::Intrawave, ck::BlockGemmPipelineVersion::v4
-#elif PP_CONV_CFG == 11
+#elif PP_CONV_CFG == 7
 #define PP_V3
 #define PP_TILE 256, 128, 128, 64, 8, 8, 32, 32, 2, 2
 #define PP_CLUSTER S<8, 32, 1>
 #define PP_LDSPAD 0
 #define PP_CSHUF S<1, 32, 1, 8>
 #define PP_PIPE ck::BlockGemmPipelineScheduler::Intrawave, ck::BlockGemmPipelineVersion::v3
-#elif PP_CONV_CFG == 12
+#elif PP_CONV_CFG == 8
 #define PP_V3
 #define PP_TILE 256, 256, 256, 32, 8, 8, 32, 32, 4, 4
 #define PP_CLUSTER S<4, 64, 1>
 #define PP_LDSPAD 0
 #define PP_CSHUF S<1, 32, 1, 8>
 #define PP_PIPE ck::BlockGemmPipelineScheduler::Intrawave, ck::BlockGemmPipelineVersion::v3
-#elif PP_CONV_CFG == 13
+#elif PP_CONV_CFG == 9
 #define PP_V3
-#define PP_TILE 256, 256, 128, 64, 16, 16, 32, 32, 4, 2
-#define PP_CLUSTER S<4, 64, 1>
-#define PP_LDSPAD 1
+#define PP_TILE 256, 256, 256, 64, 8, 8, 32, 32, 4, 4
+#define PP_CLUSTER S<8, 32, 1>
+#define PP_LDSPAD 0
 #define PP_CSHUF S<1, 32, 1, 8>
-#define PP_PIPE ck::BlockGemmPipelineScheduler::Interwave, ck::BlockGemmPipelineVersion::v1
+#define PP_PIPE ck::BlockGemmPipelineScheduler::Intrawave, ck::BlockGemmPipelineVersion::v3
 #endif
 
 #ifdef PP_V3
@@ -150,10 +131,15 @@ using Conv = ck::tensor_operation::device::DeviceGroupedConvFwdMultipleABD_Xdl_C
 using ConvBias = Conv<ck::Tuple<G_K>, ck::Tuple<F16>, BiasLeaky>;
 using ConvBiasAdd = Conv<ck::Tuple<G_K, NHWGK>, ck::Tuple<F16, F16>, BiasAddLeaky>;
 
-int run(const PPConvArgs &a) {
+// One launch over `n` images starting at image `n0` of the batch.
+int run_part(const PPConvArgs &a, int n0, int n, bool launch) {
     using idx = ck::index_t;
-    const idx G = 1, N = a.N, H = a.H, W = a.W, C = a.C, K = a.K, R = a.R, Sx = a.S;
+    const idx G = 1, N = n, H = a.H, W = a.W, C = a.C, K = a.K, R = a.R, Sx = a.S;
     const idx Ho = H + 2 * a.pad - a.dil * (R - 1), Wo = W + 2 * a.pad - a.dil * (Sx - 1);
+    const size_t in_off = (size_t)n0 * H * W * C * sizeof(F16), out_off = (size_t)n0 * Ho * Wo * K * sizeof(F16);
+    const void *x = static_cast<const char *>(a.x) + in_off;
+    const void *extra = a.extra ? static_cast<const char *>(a.extra) + out_off : nullptr;
+    void *y = static_cast<char *>(a.y) + out_off;
     // lengths in (G, N, C|K, spatial...) order; strides describe the packed NHWGC / GKYXC / NHWGK tensors (G = 1)
     const std::array<idx, 5> a_len{G, N, C, H, W}, a_str{C, H * W * C, 1, W * C, C};
     const std::array<idx, 5> b_len{G, K, C, R, Sx}, b_str{K * R * Sx * C, R * Sx * C, 1, Sx * C, C};
@@ -163,21 +149,35 @@ int run(const PPConvArgs &a) {
     const StreamConfig cfg{static_cast<hipStream_t>(a.stream), false};
     if (a.extra_mode == 0) {
         ConvBias op;
-        auto arg = op.MakeArgument(a.x, a.w, std::array<const void *, 1>{a.bias}, a.y, a_len, a_str, b_len, b_str,
+        auto arg = op.MakeArgument(x, a.w, std::array<const void *, 1>{a.bias}, y, a_len, a_str, b_len, b_str,
                                    std::array<std::array<idx, 5>, 1>{e_len}, std::array<std::array<idx, 5>, 1>{bias_str}, e_len,
                                    e_str, strides, dil, pads, pads, PassThrough{}, PassThrough{}, BiasLeaky{a.slope});
         if (!op.IsSupportedArgument(arg)) return -1;
-        op.MakeInvoker().Run(arg, cfg);
+        if (launch) op.MakeInvoker().Run(arg, cfg);
     } else {
         ConvBiasAdd op;
-        auto arg = op.MakeArgument(a.x, a.w, std::array<const void *, 2>{a.bias, a.extra}, a.y, a_len, a_str, b_len, b_str,
+        auto arg = op.MakeArgument(x, a.w, std::array<const void *, 2>{a.bias, extra}, y, a_len, a_str, b_len, b_str,
                                    std::array<std::array<idx, 5>, 2>{e_len, e_len},
                                    std::array<std::array<idx, 5>, 2>{bias_str, e_str}, e_len, e_str, strides, dil, pads, pads,
                                    PassThrough{}, PassThrough{}, BiasAddLeaky{a.slope, a.extra_mode == 1});
         if (!op.IsSupportedArgument(arg)) return -1;
-        op.MakeInvoker().Run(arg, cfg);
+        if (launch) op.MakeInvoker().Run(arg, cfg);
     }
     return 0;
+}
+
+// The device templates bound some 32-bit GEMM extents (e.g. M * K * 2 bytes <= 2 GB in the pipelined variants); a batch that
+// exceeds them is run as 2, 4 or 8 equal sub-batches (images are independent rows of the implicit GEMM).
+int run(const PPConvArgs &a) {
+    for (int parts = 1; parts <= 8; parts *= 2) {
+        if (a.N % parts) break;
+        const int n = a.N / parts;
+        if (run_part(a, 0, n, false) != 0) continue;
+        for (int p = 0; p < parts; p++)
+            if (run_part(a, p * n, n, true) != 0) return -1;
+        return 0;
+    }
+    return -1;
 }
 }  // namespace
 

@@ -162,9 +162,9 @@ PP_API int pp_pwconv_f16(const void *x, const void *w, const void *bias, const v
  * x: DEVICE (n, h, w, c_in) NHWC; w: DEVICE (c_out, ksize, ksize, c_in) (= a channels-last (c_out, c_in, k, k) weight);
  * bias fp16[c_out]; extra: DEVICE (n, ho, wo, c_out) or NULL (extra_mode 0); y: DEVICE (n, ho, wo, c_out) with
  * ho = h + 2*pad - dilation*(ksize-1).  slope = LeakyReLU slope (1.0f = no activation).  c_in, c_out multiples of 8,
- * all pointers 16-byte aligned.  config in [0, pp_conv_num_configs()) picks the workgroup tile (M x N per block:
- * 0 128x256, 1 256x128, 2 128x128, 3 128x128/128 threads, 4 128x64, 5 64x128, 6 64x64, 7 128x64/256, 8 64x128/256;
- * 9-13 the software-pipelined variants: 128x128x64 (three pipelines), 256x256x32, 256x128x64);
+ * all pointers 16-byte aligned.  config in [0, pp_conv_num_configs()) picks the workgroup tile (M x N x K-step per block):
+ * 0 128x256x32, 1 256x128x32, 2 128x128x32, 3 128x64x32 (128 threads), 4 128x64x32, 5 64x128x32, and the software-pipelined
+ * variants 6 128x128x64 (v4), 7 128x128x64 (v3), 8 256x256x32 (v3), 9 256x256x64 (v3);
  * callers time the configurations once per layer shape and keep the fastest (posepaf/fused_model.py).
  * The GEMM main loop is ROCm composable_kernel's XDL implicit-GEMM template; the epilogue functor is this library's. */
 PP_API int pp_conv_num_configs(void);

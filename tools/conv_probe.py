@@ -35,3 +35,6 @@ for tt, key, calls, best, t, tm, tf, gb in rows:
     n, c, h, w, k, r, pad, dil, mode, act = key
     print(f"{c:5d} {k:5d} {h:4d}x{w:<4d} {r} {pad:3d} {dil:3d} {mode:4d} {int(act):3d} | {calls:5d} {best:3d} {t:9.3f} {tm:10.3f} {tf:8.0f} {gb:7.0f} {100 * tt / tot:5.1f}%")
 print(f"sum over tuned shapes: {tot:.2f} ms per forward")
+print("all configurations, ms (top 8 shapes):")
+for tt, key, calls, best, t, tm, tf, gb in rows[:8]:
+    print(key, {k: round(v, 3) for k, v in fm._conv_timing[key].items()})
