@@ -142,6 +142,26 @@ def test_assembly_merge_that_sums_two_peak_ids(torch_cuda, post, oracle):
     _records_vs_oracle(recs[2], oracle.pipeline(other, 512, flip=False), "neighbour 2")
 
 
+@pytest.mark.parametrize("people,noise", [(12, 0.04), (22, 0.03), (33, 0.04), (45, 0.02)])
+def test_assembly_stress_crowded_and_noisy_scenes(torch_cuda, post, oracle, people, noise):
+    """K_C's run batching / merge / erase paths on fresh crowded scenes (more spurious peaks and skeleton merges than the
+    golden set): every image's persons, ids and scores equal the oracle's; images batched 8 at a time."""
+    from posepaf import synth
+    torch = torch_cuda
+    nets = np.stack([synth.make_net_output(people, 7000 + 13 * people + i, noise=noise, dtype=np.float16 if i % 2 else np.float32)
+                     .astype(np.float32) for i in range(8)])
+    recs = post.process(torch.from_numpy(nets).cuda(), 512)
+    checked = 0
+    for i in range(8):
+        want = oracle.pipeline(nets[i], 512)
+        if want["sort_oob"] or recs[i]["status"] & 1:   # undefined reference behaviour / more than 64 peaks of one part
+            continue
+        assert recs[i]["status"] & ~np.uint32(8) == 0
+        _records_vs_oracle(recs[i], want, f"P={people} noise={noise} img {i}")
+        checked += 1
+    assert checked >= 4
+
+
 def test_border_peaks_and_plateaus(torch_cuda, post, oracle):
     """peaks on every border/corner (clipped 3x5 / 3x3 patches) and equal-valued neighbours (plateaus)."""
     torch = torch_cuda
