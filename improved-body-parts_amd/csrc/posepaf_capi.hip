@@ -114,7 +114,10 @@ int pp_create(pp_ctx **out, int device, int max_batch, int max_h, int max_w, int
     c->max_h = max_h;
     c->max_w = max_w;
     c->maxp = max_peaks_per_part;
+    // candidate capacity per (limb, image); never below one workgroup round (256 pairs): K_B parks a round's survivors in
+    // the candidate-sized scratch arrays
     c->cap = max_peaks_per_part * max_peaks_per_part < 512 ? max_peaks_per_part * max_peaks_per_part : 512;
+    if (c->cap < 256) c->cap = 256;
     hipError_t e = pp::init_kernel_attributes();
     const size_t B = (size_t)max_batch;
     if (e == hipSuccess) e = hipMalloc(&c->d_peaks, B * PP_NUM_PART * c->maxp * sizeof(float4));

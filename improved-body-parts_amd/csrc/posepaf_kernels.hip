@@ -833,7 +833,10 @@ __device__ void connect_limb(const Sampler &smp, const LimbLds &L, int nA, int n
         nsv = 0;
     };
     for (int base = 0; base < npairs; base += kThreads, buf ^= 1) {
-        if (nsv + kThreads > cap) flush();
+        if (nsv + kThreads > cap) {
+            __syncthreads();  // the previous round's survivors (written by other waves) must be visible to flush()
+            flush();
+        }
         const int p = base + threadIdx.x;
         bool alive = false;
         float scores = 0.0f;
@@ -936,7 +939,7 @@ __device__ void connect_limb(const Sampler &smp, const LimbLds &L, int nA, int n
 
     stamp(stamps, wg, 3);
     // ---- 3. greedy matching by local dominance
-    while (true) {
+    for (int pass = 0; pass <= n; pass++) {  // every pass accepts at least the best live candidate: <= n passes
         for (int i = threadIdx.x; i < maxp; i += kThreads) {
             L.minA[i] = 0x7fffffff;
             L.minB[i] = 0x7fffffff;
@@ -1719,7 +1722,7 @@ __device__ void connect_limb_py(const Sampler &smp, const LimbLdsPy &L, int nA, 
     for (int t = threadIdx.x; t < n; t += kThreads) L.order[L.rank[t]] = t;
     __syncthreads();
     // ---- greedy pick (:393-407) as repeated acceptance of locally dominant candidates (see connect_limb)
-    while (true) {
+    for (int pass = 0; pass <= n; pass++) {  // every pass accepts at least the best live candidate: <= n passes
         for (int i = threadIdx.x; i < maxp; i += kThreads) {
             L.minA[i] = 0x7fffffff;
             L.minB[i] = 0x7fffffff;

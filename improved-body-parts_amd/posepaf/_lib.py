@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libposepaf.so")
+LIB_PATH = os.environ.get("POSEPAF_LIB") or os.path.join(_HERE, "libposepaf.so")  # override: A/B builds of the library
 
 NUM_PART, NUM_LIMB, NUM_HEAT, NUM_CH = 18, 30, 20, 50
 MAX_HUMANS = 128

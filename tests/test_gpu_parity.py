@@ -162,6 +162,54 @@ def test_assembly_stress_crowded_and_noisy_scenes(torch_cuda, post, oracle, peop
     assert checked >= 4
 
 
+def _same_record(a, b):
+    """equal in everything the record defines (slots beyond n_humans are never written)"""
+    n = int(a["n_humans"])
+    return (n == int(b["n_humans"]) and a["n_peaks"] == b["n_peaks"] and a["n_connections"] == b["n_connections"]
+            and a["status"] == b["status"] and a["humans"][:n].tobytes() == b["humans"][:n].tobytes())
+
+
+def test_limb_scoring_many_survivors_full_batch(torch_cuda, oracle):
+    """K_B parks the pairs that survive their first samples and finishes them in packed rounds; with more than 256 live
+    survivors the packed rounds start INSIDE the pair loop.  A limb map that is high everywhere keeps every pair alive
+    (64 x 64 pairs per limb), on a batch large enough that workgroups queue behind each other.  Checked against the oracle."""
+    from posepaf import synth
+    from posepaf.api import PosePostProcessor
+    torch = torch_cuda
+    rng = np.random.default_rng(11)
+    net = np.zeros((1, 50, 128, 128), np.float32)
+    net[0, :30] = 0.6 + 0.3 * rng.random((30, 128, 128), dtype=np.float32)      # every sample of every pair counts
+    ys, xs = np.meshgrid(np.arange(8, 128, 16), np.arange(8, 128, 16), indexing="ij")
+    for part in range(18):                                                          # 64 isolated peaks per part
+        net[0, 30 + part, ys + (part % 4), xs + (part // 4)] = 0.5 + 0.4 * rng.random(ys.shape, dtype=np.float32)
+    want = oracle.pipeline(net, 512, flip=False)
+    assert min(want["n_candidates"]) > 512 and not want["sort_oob"]                 # beyond the candidate capacity: flagged below
+    B = 48
+    post = PosePostProcessor(max_batch=B, max_h=128, max_w=128, max_peaks_per_part=64)
+    recs = post.process(torch.from_numpy(np.repeat(net[None], B, 0)).cuda(), 512, flip=False)
+    assert all(r["status"] & 16 for r in recs)                                       # PP_ST_CAND_OVERFLOW, loud
+    assert all(_same_record(recs[i], recs[0]) for i in range(B))
+    jl = post.read_peaks(0)
+    assert np.array_equal(jl, want["joint_list"])
+    # 28 peaks per part -> 784 pairs per limb, ALL alive after their first samples (3 packed rounds start inside the pair loop),
+    # but with min_img_size = 110 the long pairs fail `criterion2 > 0` in the end (pafprocess.cpp:92-95), so the accepted
+    # candidates (275-358 per limb) fit the capacity and everything must equal the oracle
+    r2 = np.random.default_rng(5)
+    net2 = net.copy()
+    net2[0, 30:48] = 0
+    for part in range(18):
+        sel = r2.permutation(64)[:28]
+        net2[0, 30 + part, (ys.ravel() + (part % 4))[sel], (xs.ravel() + (part // 4))[sel]] = 0.5 + 0.4 * r2.random(28, dtype=np.float32)
+    want2 = oracle.pipeline(net2, 110, flip=False)
+    assert 256 < min(want2["n_candidates"]) and max(want2["n_candidates"]) <= 512 and not want2["sort_oob"]
+    recs2 = post.process(torch.from_numpy(np.repeat(net2[None], B, 0)).cuda(), 110, flip=False)
+    for i in (0, 17, B - 1):
+        assert recs2[i]["status"] & ~np.uint32(8) == 0
+        _records_vs_oracle(recs2[i], want2, f"all-alive pairs, image {i}")
+    assert all(_same_record(recs2[i], recs2[0]) for i in range(B))
+    post.close()
+
+
 def test_border_peaks_and_plateaus(torch_cuda, post, oracle):
     """peaks on every border/corner (clipped 3x5 / 3x3 patches) and equal-valued neighbours (plateaus)."""
     torch = torch_cuda
