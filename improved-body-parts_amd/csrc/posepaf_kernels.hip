@@ -676,6 +676,123 @@ struct StdSortGE {
         // The caller computes that in parallel from the post-partition array (and the out-of-bounds condition of
         // the unguarded inserts: an element at position >= 16 with no strictly greater element before it).
     }
+
+    // ---- the same __introsort_loop, executed by ONE WAVE (all 64 lanes call it with uniform arguments).
+    // A range longer than kWaveMin is partitioned by the whole wave; shorter ranges, the median and the (rare) heapsort
+    // fallback stay on lane 0.  __unguarded_partition(first, last, pivot) with the comparator `>=`:
+    //   the left scan stops only on elements  < pivot ("left stoppers",  L_1 < L_2 < ... in index order, from `first` up),
+    //   the right scan only on elements       > pivot ("right stoppers", R_1 > R_2 > ... from `last - 1` down);
+    //   elements equal to the pivot stop neither.  The k-th round swaps L_k with R_k as long as L_k < R_k, so the result is:
+    //   swap the first k pairs (k = number of i with L_i < R_i -- monotone, so a count), return min(L_{k+1}, R_k)
+    //   (R_k now holds an element < pivot).  Stoppers outside [first, last) can never be swapped (an outside L is right of
+    //   every R and vice versa); they only decide where an unguarded scan ends, or that it leaves the array (oob).
+    // sL / sR: LDS scratch, one int per element of the range each.
+    static constexpr int kWaveMin = 16;
+    __device__ int partition_wave(int first, int last, int pivot, int lane, int *sL, int *sR) {
+        const float pv = A.key[pivot];
+        int nL = 0, nR = 0;
+        for (int base = first; base < last; base += 64) {
+            const int i = base + lane;
+            const bool is = i < last && A.key[i] < pv;
+            const unsigned long long m = __ballot(is);
+            if (is) sL[nL + __popcll(m & lanemask_lt())] = i;
+            nL += __popcll(m);
+        }
+        for (int base = last - 1; base >= first; base -= 64) {
+            const int j = base - lane;
+            const bool is = j >= first && A.key[j] > pv;
+            const unsigned long long m = __ballot(is);
+            if (is) sR[nR + __popcll(m & lanemask_lt())] = j;
+            nR += __popcll(m);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int mn = nL < nR ? nL : nR;
+        int k = 0;
+        for (int base = 0; base < mn; base += 64) {
+            const int i = base + lane;
+            k += __popcll(__ballot(i < mn && sL[i] < sR[i]));
+        }
+        for (int base = 0; base < k; base += 64) {
+            const int i = base + lane;
+            if (i < k) swp(sL[i], sR[i]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        int cut;
+        if (k >= 1) {
+            const int rk = sR[k - 1];
+            cut = (k < nL && sL[k] < rk) ? sL[k] : rk;
+        } else if (nL > 0) {
+            cut = sL[0];
+        } else {  // no element < pivot in the range: the reference's scan runs on into the following elements
+            cut = n;
+            for (int base = last; base < n && cut == n; base += 64) {
+                const int i = base + lane;
+                const unsigned long long m = __ballot(i < n && A.key[i] < pv);
+                if (m) cut = base + __ffsll((long long)m) - 1;
+            }
+            if (cut == n) oob = true;
+        }
+        if (k == 0 && nR == 0) {  // no element > pivot in the range: the right scan runs down past the pivot
+            bool found = false;
+            for (int base = first - 1; base >= 0 && !found; base -= 64) {
+                const int j = base - lane;
+                found = __ballot(j >= 0 && A.key[j] > pv) != 0;
+            }
+            if (!found) oob = true;
+        }
+        return cut;
+    }
+    __device__ void run_partitions_wave(int *stk, int lane, int *sL, int *sR) {
+        oob = false;
+        if (n <= 0) return;
+        int lg = 0;
+        while ((1 << (lg + 1)) <= n) lg++;
+        int sp = 1;
+        stk[0] = 0;  // every lane stores the same values
+        stk[1] = n;
+        stk[2] = 2 * lg;
+        while (sp > 0) {
+            --sp;
+            const int first = stk[3 * sp];
+            int last = stk[3 * sp + 1];
+            int depth = stk[3 * sp + 2];
+            while (last - first > 16) {
+                if (depth == 0) {
+                    if (lane == 0) heapsort(first, last);
+                    __builtin_amdgcn_wave_barrier();
+                    break;
+                }
+                --depth;
+                const int mid = first + (last - first) / 2;
+                int cut = 0;
+                if (last - first > kWaveMin) {
+                    if (lane == 0) move_median_to_first(first, first + 1, mid, last - 1);
+                    __builtin_amdgcn_wave_barrier();
+                    cut = partition_wave(first + 1, last, first, lane, sL, sR);
+                } else {
+                    bool o = false;
+                    if (lane == 0) {
+                        const bool keep = oob;
+                        oob = false;
+                        move_median_to_first(first, first + 1, mid, last - 1);
+                        cut = unguarded_partition(first + 1, last, first);
+                        o = oob;
+                        oob = keep;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    cut = __shfl(cut, 0);
+                    if (__ballot(o)) oob = true;
+                }
+                if (sp < kSortStack) {
+                    stk[3 * sp] = cut;
+                    stk[3 * sp + 1] = last;
+                    stk[3 * sp + 2] = depth;
+                    ++sp;
+                }
+                last = cut;
+            }
+        }
+    }
 };
 
 // One (a, b) peak pair: pafprocess.cpp:66-106 + get_paf_scores :311-327, split so that the samples can be taken in two
@@ -885,52 +1002,77 @@ __device__ void connect_limb(const Sampler &smp, const LimbLds &L, int nA, int n
     }
     __syncthreads();
 
-    // ---- 2. ranks
+    // ---- 2. ranks (counting: gt = keys strictly greater, eq = keys equal incl. itself; 4 VALU per comparison pair)
     bool tie = false;
     for (int t = threadIdx.x; t < n; t += kThreads) {
         const float kt = L.key[t];
-        int gt = 0, eq_later = 0, eq_any = 0;
+        int gt = 0, eq = 0;
+#pragma unroll 4
         for (int j = 0; j < n; j++) {
             const float kj = L.key[j];  // broadcast read
             gt += kj > kt;
-            if (kj == kt) {
-                eq_any += j != t;
-                eq_later += j > t;
-            }
+            eq += kj == kt;
         }
         // n <= 16 is a pure insertion sort with `>=`: an element moves in front of every earlier EQUAL element, so
-        // among equals the later-generated comes first.  Without ties eq_later is 0 and the order is unique.
+        // among equals the later-generated comes first.  Without ties the order is unique.  (With ties and n > 16 the
+        // ranks come from the emulation below instead.)
+        int eq_later = 0;
+        if (eq > 1 && n <= 16)
+            for (int j = t + 1; j < n; j++) eq_later += L.key[j] == kt;
         L.rank[t] = gt + eq_later;
         L.state[t] = 0;
-        tie |= eq_any > 0;
+        tie |= eq > 1;
     }
     const int any_tie = __syncthreads_or(tie);
     if (n > 16 && any_tie) {
         for (int t = threadIdx.x; t < n; t += kThreads) L.order[t] = t;
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (wave == 0) {  // one wave; the preliminary ranks and the state array serve as its scratch
             LdsSortAcc acc{L.key, L.order};  // permuted in place: the generation-indexed keys are no longer needed
             StdSortGE<LdsSortAcc> srt(acc, n);
-            srt.run_partitions(s_stack);
-            if (srt.oob) s_oob = 1;
+            srt.run_partitions_wave(s_stack, lane, L.rank, L.state);
+            if (lane == 0 && srt.oob) s_oob = 1;
         }
         __syncthreads();
-        // final insertion sort in closed form, one thread per position p of the post-partition array
+        // Final insertion sort in closed form from the post-partition array: position p ends at rank
+        // (#keys > key[p]) + (#equal keys after p).  The reference's unguarded insert of an element at p >= 16 runs off
+        // the array when nothing strictly greater precedes it, i.e. when key[p] >= max(key[0..p-1]): inclusive prefix
+        // maxima by a doubling scan in the two scratch arrays.
+        float *pm = reinterpret_cast<float *>(L.state), *pm2 = reinterpret_cast<float *>(L.rank);
+        for (int p = threadIdx.x; p < n; p += kThreads) pm[p] = L.key[p];
+        __syncthreads();
+        for (int d = 1; d < n; d <<= 1) {
+            for (int p = threadIdx.x; p < n; p += kThreads) {
+                const float v = pm[p];
+                pm2[p] = p >= d ? fmaxf(v, pm[p - d]) : v;
+            }
+            __syncthreads();
+            float *tmp = pm;
+            pm = pm2;
+            pm2 = tmp;
+        }
         bool oob = false;
+        for (int p = 16 + threadIdx.x; p < n; p += kThreads) oob |= L.key[p] >= pm[p - 1];
+        if (__syncthreads_or(oob) && threadIdx.x == 0) s_oob = 1;  // (barrier: the scratch arrays are rewritten below)
         for (int p = threadIdx.x; p < n; p += kThreads) {
             const float kp = L.key[p];
-            int gt = 0, eq_after = 0, gt_before = 0;
+            int gt = 0, eq = 0;
+#pragma unroll 4
             for (int q = 0; q < n; q++) {
                 const float kq = L.key[q];  // broadcast read
                 gt += kq > kp;
-                eq_after += (kq == kp) && (q > p);
-                gt_before += (kq > kp) && (q < p);
+                eq += kq == kp;
             }
+            int eq_after = 0;
+            if (eq > 1)
+                for (int q = p + 1; q < n; q++) eq_after += L.key[q] == kp;
             L.rank[L.order[p]] = gt + eq_after;
-            oob |= (p >= 16) && (gt_before == 0);  // the reference's unguarded insert would run off the array
         }
-        if (__syncthreads_or(oob) && threadIdx.x == 0) s_oob = 1;
-        for (int t = threadIdx.x; t < n; t += kThreads) L.order[L.rank[t]] = t;
+        __syncthreads();
+        for (int t = threadIdx.x; t < n; t += kThreads) {
+            L.order[L.rank[t]] = t;
+            L.state[t] = 0;
+        }
     } else {
         for (int t = threadIdx.x; t < n; t += kThreads) L.order[L.rank[t]] = t;
     }

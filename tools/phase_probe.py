@@ -15,7 +15,7 @@ from posepaf.api import PosePostProcessor
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 L = _lib.load()
 post = PosePostProcessor(max_batch=B, max_h=128, max_w=128, max_peaks_per_part=64)
-for P in (2, 6, 15, 30, 45):
+for P in (6, 15, 30):
     nets = np.stack([synth.make_net_output(P, 500 + i, dtype=np.float16) for i in range(16)])
     dev = torch.from_numpy(np.concatenate([nets] * (B // 16))).cuda()
     post.process(dev, 512)
@@ -40,6 +40,10 @@ for P in (2, 6, 15, 30, 45):
             if len(hit):
                 print(f"P={P:2d} K_C: id-summing merges in scenes (P, seed): " + ", ".join(f"({P},{500 + int(i)})" for i in hit))
             print(f"P={P:2d} K_C: one-by-one connections/img mean {raw[:, 4].mean():5.1f} max {raw[:, 4].max():3d}; cycles in them mean {raw[:, 5].mean()/1e3:6.1f} kcyc; id-summing merges (tables abandoned) total {int(raw[:, 6].sum())}")
+        if name == "K_B":
+            tot = s[:, len(labels)] - s[:, 0]
+            for w in np.argsort(-tot)[:4]:
+                print(f"P={P:2d} K_B slowest wg: total {tot[w]/1e3:6.1f} kcyc = " + "  ".join(f"{lab} {d[w, i]/1e3:6.1f}" for i, lab in enumerate(labels)))
         print(f"P={P:2d} {name}: wgs {ok.sum():5d}  kernel span {span/1e3:8.1f} kcyc | " +
               "  ".join(f"{lab} mean {d[:, i].mean()/1e3:6.1f} max {d[:, i].max()/1e3:6.1f}" for i, lab in enumerate(labels)) +
               f" | wg total mean {(s[:, len(labels)] - s[:, 0]).mean()/1e3:6.1f} max {(s[:, len(labels)] - s[:, 0]).max()/1e3:6.1f} kcyc")
