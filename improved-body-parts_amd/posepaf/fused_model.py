@@ -29,7 +29,7 @@ USE_FUSED_CONV = True
 _conv_choice: dict = {}   # shape key -> tile configuration id, or -1 = MIOpen convolution + k_bias_act pass
 _conv_timing: dict = {}   # shape key -> {"miopen": ms, cfg: ms, ...} measured by the autotune (diagnostics)
 _conv_calls: dict = {}    # shape key -> number of forward() calls since import (diagnostics)
-_TUNE_REPS = 3
+_TUNE_REPS = 5
 
 
 def conv_choices() -> dict:
@@ -166,16 +166,18 @@ class FConv(nn.Module):
         from . import _lib
         L = _lib.load()
 
-        def timed(fn):
+        def timed(fn):   # median of _TUNE_REPS single-launch timings after one warm-up
             fn()
             torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+            ts = []
             for _ in range(_TUNE_REPS):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
                 fn()
-            e1.record()
-            torch.cuda.synchronize()
-            return e0.elapsed_time(e1) / _TUNE_REPS
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            return sorted(ts)[len(ts) // 2]
 
         best, best_t = -1, timed(lambda: hip_bias_act_(self.conv_only(x), self.bias, res, self.act, post))
         times = {"miopen": best_t}
