@@ -517,7 +517,8 @@ constexpr int kSortStack = 48;
 
 // libstdc++ std::sort (introsort, threshold 16, depth limit 2*floor(log2 n), heapsort fallback, final
 // insertion sort) with the reference's comparator a.overall_score >= b.overall_score
-// (pafprocess.cpp:109, :333-335), executed by ONE lane on LDS arrays (key[i], gen[i]).  Tied keys are common on
+// (pafprocess.cpp:109, :333-335), executed on LDS arrays (key[i], gen[i]) by one lane (run_partitions) or by one
+// wave with lane-parallel partitions (run_partitions_wave, the form K_B uses).  Tied keys are common on
 // this path (duplicate peaks) and the order among ties decides the greedy matching, so the algorithm itself is
 // part of the result; it is restated step for step (see oracle/posepaf_oracle.c for the same restatement in C).
 // It only runs when a limb has MORE than 16 accepted candidates AND at least one exact tie -- otherwise the
@@ -605,81 +606,14 @@ struct StdSortGE {
         else if (ge(vm, vc)) swp(result, c);
         else swp(result, m);
     }
-    __device__ int unguarded_partition(int first, int last, int pivot) {
-        const SortElem pv = get(pivot);  // the pivot slot is never written during the partition
-        while (true) {
-            while (true) {
-                if (first >= n) {
-                    oob = true;
-                    break;
-                }
-                if (!ge(get(first), pv)) break;
-                ++first;
-            }
-            --last;
-            while (true) {
-                if (last < 0) {
-                    oob = true;
-                    break;
-                }
-                if (!ge(pv, get(last))) break;
-                --last;
-            }
-            if (!(first < last)) return first;
-            swp(first, last);
-            ++first;
-        }
-    }
-    // stack: LDS scratch of 3*kSortStack ints (explicit form of __introsort_loop's recursion)
-    // the __introsort_loop part of std::sort: partitions (and the heapsort fallback) down to pieces of <= 16 elements
-    __device__ void run_partitions(int *stk) {
-        oob = false;
-        if (n <= 0) return;
-        int lg = 0;
-        while ((1 << (lg + 1)) <= n) lg++;
-        int sp = 0;
-        stk[0] = 0;
-        stk[1] = n;
-        stk[2] = 2 * lg;
-        sp = 1;
-        while (sp > 0) {
-            --sp;
-            const int first = stk[3 * sp];
-            int last = stk[3 * sp + 1];
-            int depth = stk[3 * sp + 2];
-            // libstdc++ recurses into the right part and loops on the left part; the parts are disjoint, so the
-            // order in which they are processed does not change the result.
-            while (last - first > 16) {
-                if (depth == 0) {
-                    heapsort(first, last);
-                    break;
-                }
-                --depth;
-                const int mid = first + (last - first) / 2;
-                move_median_to_first(first, first + 1, mid, last - 1);
-                // NOTE: with the non-strict comparator the left scan may run past `last` (every element of the range
-                // >= pivot) and stop on an element of a neighbouring range; libstdc++ then simply continues with
-                // [first, cut) -- reproduced as is (cut <= n always: the scan stops at the array end, flagged oob)
-                const int cut = unguarded_partition(first + 1, last, first);
-                if (sp < kSortStack) {
-                    stk[3 * sp] = cut;
-                    stk[3 * sp + 1] = last;
-                    stk[3 * sp + 2] = depth;
-                    ++sp;
-                }
-                last = cut;
-            }
-        }
-        // __final_insertion_sort is NOT emulated step by step: an insertion sort with `>=` puts every element just
-        // after the last strictly greater one, i.e. in front of all equal ones, whatever the distances -- so its
-        // result is "descending key, ties in REVERSE of their order in the array as the partitioning left it".
-        // The caller computes that in parallel from the post-partition array (and the out-of-bounds condition of
-        // the unguarded inserts: an element at position >= 16 with no strictly greater element before it).
-    }
-
-    // ---- the same __introsort_loop, executed by ONE WAVE (all 64 lanes call it with uniform arguments).
-    // A range longer than kWaveMin is partitioned by the whole wave; shorter ranges, the median and the (rare) heapsort
-    // fallback stay on lane 0.  __unguarded_partition(first, last, pivot) with the comparator `>=`:
+    // ---- the __introsort_loop part of std::sort (partitions, and the heapsort fallback, down to pieces of <= 16
+    // elements), executed by ONE WAVE: all 64 lanes call it with uniform arguments; every partition is done by the whole
+    // wave, the median-of-3 and the (rare) heapsort fallback by lane 0.  The explicit stack (3 * kSortStack ints of LDS)
+    // replaces the recursion: libstdc++ recurses into the right part and loops on the left one; the parts are disjoint, so
+    // the order in which they are processed does not change the result.  With the non-strict comparator a left scan may run
+    // past `last` (every element of the range >= pivot) and stop in a neighbouring range; libstdc++ then simply continues with
+    // [first, cut) -- reproduced as is (a scan that would leave the array stops at its end and sets oob).
+    // __unguarded_partition(first, last, pivot) with the comparator `>=`:
     //   the left scan stops only on elements  < pivot ("left stoppers",  L_1 < L_2 < ... in index order, from `first` up),
     //   the right scan only on elements       > pivot ("right stoppers", R_1 > R_2 > ... from `last - 1` down);
     //   elements equal to the pivot stop neither.  The k-th round swaps L_k with R_k as long as L_k < R_k, so the result is:
@@ -687,7 +621,6 @@ struct StdSortGE {
     //   (R_k now holds an element < pivot).  Stoppers outside [first, last) can never be swapped (an outside L is right of
     //   every R and vice versa); they only decide where an unguarded scan ends, or that it leaves the array (oob).
     // sL / sR: LDS scratch, one int per element of the range each.
-    static constexpr int kWaveMin = 16;
     __device__ int partition_wave(int first, int last, int pivot, int lane, int *sL, int *sR) {
         const float pv = A.key[pivot];
         int nL = 0, nR = 0;
@@ -764,25 +697,9 @@ struct StdSortGE {
                 }
                 --depth;
                 const int mid = first + (last - first) / 2;
-                int cut = 0;
-                if (last - first > kWaveMin) {
-                    if (lane == 0) move_median_to_first(first, first + 1, mid, last - 1);
-                    __builtin_amdgcn_wave_barrier();
-                    cut = partition_wave(first + 1, last, first, lane, sL, sR);
-                } else {
-                    bool o = false;
-                    if (lane == 0) {
-                        const bool keep = oob;
-                        oob = false;
-                        move_median_to_first(first, first + 1, mid, last - 1);
-                        cut = unguarded_partition(first + 1, last, first);
-                        o = oob;
-                        oob = keep;
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    cut = __shfl(cut, 0);
-                    if (__ballot(o)) oob = true;
-                }
+                if (lane == 0) move_median_to_first(first, first + 1, mid, last - 1);
+                __builtin_amdgcn_wave_barrier();
+                const int cut = partition_wave(first + 1, last, first, lane, sL, sR);
                 if (sp < kSortStack) {
                     stk[3 * sp] = cut;
                     stk[3 * sp + 1] = last;
