@@ -210,6 +210,34 @@ def test_limb_scoring_many_survivors_full_batch(torch_cuda, oracle):
     post.close()
 
 
+@pytest.mark.parametrize("npk,size", [(8, 512), (20, 512), (28, 110)])
+def test_massive_ties_terminate_and_are_flagged(torch_cuda, post, oracle, npk, size):
+    """Constant limb maps and equal peak scores: hundreds of exactly tied candidates per limb, the case in which the reference's
+    `>=` comparator drives std::sort's unguarded scans off the array (undefined behaviour there).  The kernel must finish,
+    raise PP_ST_SORT_UNDEFINED where the oracle's restatement sees the out-of-bounds scan, and leave neighbours untouched."""
+    from posepaf import synth
+    torch = torch_cuda
+    rng = np.random.default_rng(3)
+    net = np.zeros((1, 50, 128, 128), np.float32)
+    net[0, :30] = 0.8
+    ys, xs = np.meshgrid(np.arange(8, 128, 16), np.arange(8, 128, 16), indexing="ij")
+    for part in range(18):
+        sel = rng.permutation(64)[:npk]
+        net[0, 30 + part, (ys.ravel() + (part % 4))[sel], (xs.ravel() + (part // 4))[sel]] = 0.9
+    want = oracle.pipeline(net, size, flip=False)
+    assert want["sort_oob"]
+    other = synth.make_net_output(7, 99, dtype=np.float32, flip=False)
+    recs = post.process(torch.from_numpy(np.stack([other, net, net, other])).cuda(), size, flip=False)
+    for i in (1, 2):
+        assert recs[i]["status"] & 8, "PP_ST_SORT_UNDEFINED expected"
+        assert recs[i]["status"] & ~np.uint32(8) == 0
+        assert recs[i]["n_peaks"] == len(want["joint_list"]) and recs[i]["n_humans"] > 0
+    w_other = oracle.pipeline(other, size, flip=False)
+    if not w_other["sort_oob"]:
+        _records_vs_oracle(recs[0], w_other, "neighbour 0")
+        _records_vs_oracle(recs[3], w_other, "neighbour 3")
+
+
 def test_border_peaks_and_plateaus(torch_cuda, post, oracle):
     """peaks on every border/corner (clipped 3x5 / 3x3 patches) and equal-valued neighbours (plateaus)."""
     torch = torch_cuda
