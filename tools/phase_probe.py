@@ -30,7 +30,7 @@ for P in (6, 15, 30):
         torch.cuda.synchronize()
         L.pp_debug_set_stamps(None)
         s = st.cpu().numpy().reshape(nwg, 8)
-        ok = s[:, 0] > 0
+        ok = (s[:, :len(labels) + 1] > 0).all(axis=1)   # workgroups that ran every phase (empty limbs return early)
         s = s[ok]
         raw = s
         d = np.diff(s[:, :len(labels) + 1], axis=1)
