@@ -159,6 +159,74 @@ extern "C" int pp_upsample2_f16(const void *x, void *y, long n, int h_in, int w_
     return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
 }
 
+// ------------------------------------------------------------------------------------------------ SE squeeze
+// Channel means of an NHWC fp16 activation (models/layers_transposed.py SELayer: AdaptiveAvgPool2d(1)): two passes.
+// (1) grid (splits, n): every workgroup sums its slice of the pixels, 8 channels (one 16-byte vector) per thread and
+//     256 / (c/8) pixels in flight per step, fp32 accumulation, LDS reduction over the pixel lanes -> partial[n][split][c];
+// (2) one thread per (n, c): sum of the splits / (h*w) -> fp16.
+namespace {
+__global__ __launch_bounds__(256) void k_channel_sum(const uint4 *__restrict__ x, float *__restrict__ partial, long hw, int cvec,
+                                                     int splits) {
+    __shared__ float s_acc[256 * 8];
+    const int n = blockIdx.y, split = blockIdx.x;
+    const int plan = 256 / cvec;                 // pixel lanes
+    const int v = threadIdx.x % cvec, pl = threadIdx.x / cvec;
+    const long per = (hw + splits - 1) / splits, p0 = (long)split * per, p1 = p0 + per < hw ? p0 + per : hw;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (pl < plan) {
+        const uint4 *base = x + (size_t)n * hw * cvec + v;
+#pragma unroll 4
+        for (long p = p0 + pl; p < p1; p += plan) {
+            const uint4 q = base[(size_t)p * cvec];
+            const __half2 *h = reinterpret_cast<const __half2 *>(&q);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float2 f = __half22float2(h[k]);
+                acc[2 * k] += f.x;
+                acc[2 * k + 1] += f.y;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) s_acc[threadIdx.x * 8 + k] = acc[k];
+    __syncthreads();
+    if (threadIdx.x < cvec) {  // pixel lane 0 of every channel vector adds the other lanes
+        float *out = partial + ((size_t)n * splits + split) * cvec * 8 + (size_t)threadIdx.x * 8;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            float t = 0.f;
+            for (int l = 0; l < plan; l++) t += s_acc[(l * cvec + threadIdx.x) * 8 + k];
+            out[k] = t;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_channel_mean_finish(const float *__restrict__ partial, __half *__restrict__ out, int n_images,
+                                                             int c, int splits, float inv_hw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_images * c) return;
+    const int n = i / c, ch = i - n * c;
+    float t = 0.f;
+    for (int s = 0; s < splits; s++) t += partial[((size_t)n * splits + s) * c + ch];
+    out[i] = __float2half_rn(t * inv_hw);
+}
+}  // namespace
+
+extern "C" int pp_channel_mean_f16(const void *x, void *partial_ws, void *out, int n, long hw, int channels, int splits,
+                                   void *stream) {
+    if (!x || !partial_ws || !out || n <= 0 || hw <= 0 || channels <= 0 || (channels & 7) || channels > 2048 || splits <= 0 ||
+        splits > 65535 || (reinterpret_cast<uintptr_t>(x) & 15))
+        return PP_ERR_BAD_ARG;
+    const int cvec = channels / 8;
+    if (cvec > 256) return PP_ERR_BAD_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_channel_sum, dim3(splits, n), dim3(256), 0, st, static_cast<const uint4 *>(x),
+                       static_cast<float *>(partial_ws), hw, cvec, splits);
+    const int total = n * channels;
+    hipLaunchKernelGGL(k_channel_mean_finish, dim3((total + 255) / 256), dim3(256), 0, st, static_cast<const float *>(partial_ws),
+                       static_cast<__half *>(out), n, channels, splits, 1.0f / (float)hw);
+    return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
+}
+
 // ------------------------------------------------------------------------------------------------ A0 pre-processing
 // utils/parse_skeletons.py:52-73 + utils/util.py:44-65 for a batch of equally sized BGR uint8 images (scale 1):
 // pad bottom/right to a multiple of `pad_to` with `pad_value`, x / 255 -> float, and emit each image followed by the

@@ -87,6 +87,20 @@ def upsample2(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def channel_mean(x: torch.Tensor) -> torch.Tensor:
+    """(n, c, h, w) -> (n, c) mean over the pixels (the SE squeeze); HIP kernel on channels-last fp16, torch elsewhere."""
+    n, c, h, w = x.shape
+    if not (x.is_cuda and x.dtype == torch.float16 and c % 8 == 0 and c <= 2048):
+        return x.mean(dim=(2, 3))
+    from . import _lib
+    x = _cl(x)
+    splits = max(1, min(h * w, -(-1024 // n)))
+    ws = torch.empty((n, splits, c), dtype=torch.float32, device=x.device)
+    out = torch.empty((n, c), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.load().pp_channel_mean_f16(_ptr(x), _ptr(ws), _ptr(out), n, h * w, c, splits, _stream(x)))
+    return out
+
+
 def _use_hip(x: torch.Tensor, c_out: int) -> bool:
     return x.is_cuda and x.dtype == torch.float16 and c_out % 8 == 0
 
@@ -271,7 +285,7 @@ class FSE(nn.Module):
         self.fc1, self.fc2 = se.fc[0], se.fc[2]
 
     def forward(self, x):
-        y = x.mean(dim=(2, 3))
+        y = channel_mean(x)
         y = torch.sigmoid(self.fc2(F.leaky_relu(self.fc1(y), 0.01)))
         return x * y[:, :, None, None]
 

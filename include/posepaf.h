@@ -145,6 +145,10 @@ PP_API int pp_bias_act_f16(void *y, const void *bias, const void *residual, cons
                            float slope, int has_act, void *stream);
 PP_API int pp_maxpool2_f16(const void *x, void *y, long n, int h_out, int w_out, int channels, void *stream);
 PP_API int pp_upsample2_f16(const void *x, void *y, long n, int h_in, int w_in, int channels, void *stream);
+/* SE squeeze (models/layers_transposed.py SELayer, AdaptiveAvgPool2d(1)): out[n][c] = mean over the h*w pixels of the NHWC fp16
+ * activation x (n, hw, channels), fp32 accumulation.  partial_ws: DEVICE float[n][splits][channels] scratch; splits = number of
+ * workgroups per image (pick n*splits >= ~1024).  channels % 8 == 0, channels <= 2048. */
+PP_API int pp_channel_mean_f16(const void *x, void *partial_ws, void *out, int n, long hw, int channels, int splits, void *stream);
 
 /* Fused point-wise (1x1) convolution on the matrix cores (v_mfma_f32_32x32x16_f16), fp16 in/out, fp32 accumulate:
  *   y[m][n] = act(sum_k x[m][k] * w[n][k] + bias[n] (+ residual[m][n])) (+ post[m][n])
