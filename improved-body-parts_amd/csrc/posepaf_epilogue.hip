@@ -211,6 +211,49 @@ __global__ __launch_bounds__(256) void k_channel_mean_finish(const float *__rest
 }
 }  // namespace
 
+// SE excitation: y[n][p][c] = x[n][p][c] * scale[n][c], 16-byte vectors, product rounded once to fp16 like torch's fp16 multiply
+namespace {
+__global__ __launch_bounds__(256) void k_channel_scale(const uint4 *__restrict__ x, const uint4 *__restrict__ scale, uint4 *__restrict__ y,
+                                                       long hw, int cvec) {
+    // grid (pixel blocks, n): a thread keeps ONE channel vector (its scale stays in registers) and walks over pixels
+    const int n = blockIdx.y, plan = 256 / cvec, v = threadIdx.x % cvec, pl = threadIdx.x / cvec;
+    if (pl >= plan) return;
+    const uint4 b = scale[(size_t)n * cvec + v];
+    const __half2 *bh = reinterpret_cast<const __half2 *>(&b);
+    float2 fb[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) fb[k] = __half22float2(bh[k]);
+    const size_t base = (size_t)n * hw * cvec + v;
+#pragma unroll 4
+    for (long p = (long)blockIdx.x * plan + pl; p < hw; p += (long)gridDim.x * plan) {
+        const uint4 a = x[base + (size_t)p * cvec];
+        uint4 r;
+        const __half2 *ah = reinterpret_cast<const __half2 *>(&a);
+        __half2 *rh = reinterpret_cast<__half2 *>(&r);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float2 fa = __half22float2(ah[k]);
+            rh[k] = __float22half2_rn(make_float2(fa.x * fb[k].x, fa.y * fb[k].y));
+        }
+        y[base + (size_t)p * cvec] = r;
+    }
+}
+}  // namespace
+
+extern "C" int pp_channel_scale_f16(const void *x, const void *scale, void *y, int n, long hw, int channels, void *stream) {
+    if (!x || !scale || !y || n <= 0 || hw <= 0 || channels <= 0 || (channels & 7) ||
+        ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(y)) & 15))
+        return PP_ERR_BAD_ARG;
+    const int cvec = channels / 8;
+    if (cvec > 256 || n > 65535) return PP_ERR_BAD_ARG;
+    const long per_block = 256 / cvec;  // pixels per workgroup step
+    long bx = (hw + per_block * 8 - 1) / (per_block * 8);  // about 8 steps per thread
+    bx = bx < 1 ? 1 : (bx > 4096 ? 4096 : bx);
+    hipLaunchKernelGGL(k_channel_scale, dim3((unsigned)bx, n), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const uint4 *>(x), static_cast<const uint4 *>(scale), static_cast<uint4 *>(y), hw, cvec);
+    return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
+}
+
 extern "C" int pp_channel_mean_f16(const void *x, void *partial_ws, void *out, int n, long hw, int channels, int splits,
                                    void *stream) {
     if (!x || !partial_ws || !out || n <= 0 || hw <= 0 || channels <= 0 || (channels & 7) || channels > 2048 || splits <= 0 ||

@@ -101,6 +101,19 @@ def channel_mean(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def channel_scale(x: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
+    """x * s[:, :, None, None] (the SE excitation); HIP kernel on channels-last fp16, torch elsewhere."""
+    n, c, h, w = x.shape
+    if not (x.is_cuda and x.dtype == torch.float16 and s.dtype == torch.float16 and c % 8 == 0):
+        return x * s[:, :, None, None]
+    from . import _lib
+    x = _cl(x)
+    s = s.contiguous()
+    y = torch.empty_like(x, memory_format=torch.channels_last)
+    _lib.check(_lib.load().pp_channel_scale_f16(_ptr(x), _ptr(s), _ptr(y), n, h * w, c, _stream(x)))
+    return y
+
+
 def _use_hip(x: torch.Tensor, c_out: int) -> bool:
     return x.is_cuda and x.dtype == torch.float16 and c_out % 8 == 0
 
@@ -287,7 +300,7 @@ class FSE(nn.Module):
     def forward(self, x):
         y = channel_mean(x)
         y = torch.sigmoid(self.fc2(F.leaky_relu(self.fc1(y), 0.01)))
-        return x * y[:, :, None, None]
+        return channel_scale(x, y)
 
 
 class FFeature(nn.Module):

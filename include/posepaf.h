@@ -149,6 +149,8 @@ PP_API int pp_upsample2_f16(const void *x, void *y, long n, int h_in, int w_in, 
  * activation x (n, hw, channels), fp32 accumulation.  partial_ws: DEVICE float[n][splits][channels] scratch; splits = number of
  * workgroups per image (pick n*splits >= ~1024).  channels % 8 == 0, channels <= 2048. */
 PP_API int pp_channel_mean_f16(const void *x, void *partial_ws, void *out, int n, long hw, int channels, int splits, void *stream);
+/* SE excitation: y[n][p][c] = x[n][p][c] * scale[n][c] on NHWC fp16 (x: (n, hw, channels), scale: fp16 (n, channels)); y may be x. */
+PP_API int pp_channel_scale_f16(const void *x, const void *scale, void *y, int n, long hw, int channels, void *stream);
 
 /* Fused point-wise (1x1) convolution on the matrix cores (v_mfma_f32_32x32x16_f16), fp16 in/out, fp32 accumulate:
  *   y[m][n] = act(sum_k x[m][k] * w[n][k] + bias[n] (+ residual[m][n])) (+ post[m][n])

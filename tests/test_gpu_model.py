@@ -25,6 +25,8 @@ def test_helper_kernels_match_torch():
             if post is not None:
                 ref = ref + post.float()
             assert torch.equal(y, ref.half()), (n, c, h, w, res is not None, act, post is not None)
+        sc = torch.rand(n, c, generator=g).cuda().half()
+        assert torch.equal(fm.channel_scale(x, sc), x * sc[:, :, None, None])
         m = fm.channel_mean(x)
         assert m.shape == (n, c) and torch.allclose(m.float(), x.float().mean(dim=(2, 3)), rtol=0, atol=2e-3)
         assert torch.equal(fm.maxpool2(x), torch.nn.functional.max_pool2d(x, 2, 2))
