@@ -159,6 +159,56 @@ extern "C" int pp_upsample2_f16(const void *x, void *y, long n, int h_in, int w_
     return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
 }
 
+// ------------------------------------------------------------------------------------------------ three-way add
+// y = a + b (+ c), fp32 sum rounded once: the hourglass's `up1 + up2` and the next stage's `+ cache` in one pass over the
+// activation (posepaf/fused_model.py FHourglass; reference: models/layers_transposed.py Hourglass.forward, models/posenet.py)
+namespace {
+template <bool HAS_C>
+__global__ __launch_bounds__(256) void k_add3(const uint4 *__restrict__ a, const uint4 *__restrict__ b, const uint4 *__restrict__ c,
+                                              uint4 *__restrict__ y, long nvec) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
+        const uint4 qa = a[v], qb = b[v];
+        uint4 qc, r;
+        if (HAS_C) qc = c[v];
+        const __half2 *ha = reinterpret_cast<const __half2 *>(&qa), *hb = reinterpret_cast<const __half2 *>(&qb);
+        const __half2 *hc = reinterpret_cast<const __half2 *>(&qc);
+        __half2 *hr = reinterpret_cast<__half2 *>(&r);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float2 f = __half22float2(ha[k]);
+            const float2 g = __half22float2(hb[k]);
+            f.x += g.x;
+            f.y += g.y;
+            if (HAS_C) {
+                const float2 h = __half22float2(hc[k]);
+                f.x += h.x;
+                f.y += h.y;
+            }
+            hr[k] = __float22half2_rn(f);
+        }
+        y[v] = r;
+    }
+}
+}  // namespace
+
+extern "C" int pp_add3_f16(const void *a, const void *b, const void *c, void *y, long n_elems, void *stream) {
+    if (!a || !b || !y || n_elems <= 0 || (n_elems & 7) ||
+        ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
+          reinterpret_cast<uintptr_t>(y)) & 15))
+        return PP_ERR_BAD_ARG;
+    const long nvec = n_elems / 8;
+    const dim3 grid(grid_for(nvec)), block(256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (c)
+        hipLaunchKernelGGL(k_add3<true>, grid, block, 0, st, static_cast<const uint4 *>(a), static_cast<const uint4 *>(b),
+                           static_cast<const uint4 *>(c), static_cast<uint4 *>(y), nvec);
+    else
+        hipLaunchKernelGGL(k_add3<false>, grid, block, 0, st, static_cast<const uint4 *>(a), static_cast<const uint4 *>(b),
+                           static_cast<const uint4 *>(nullptr), static_cast<uint4 *>(y), nvec);
+    return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
+}
+
 // ------------------------------------------------------------------------------------------------ SE squeeze
 // Channel means of an NHWC fp16 activation (models/layers_transposed.py SELayer: AdaptiveAvgPool2d(1)): two passes.
 // (1) grid (splits, n): every workgroup sums its slice of the pixels, 8 channels (one 16-byte vector) per thread and

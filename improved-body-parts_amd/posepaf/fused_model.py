@@ -87,6 +87,19 @@ def upsample2(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def add3(a: torch.Tensor, b: torch.Tensor, c=None) -> torch.Tensor:
+    """a + b (+ c) in one pass; HIP kernel on channels-last fp16, torch elsewhere."""
+    if not (a.is_cuda and a.dtype == torch.float16 and a.numel() % 8 == 0 and a.shape == b.shape
+            and (c is None or c.shape == a.shape)):
+        return a + b if c is None else a + b + c
+    from . import _lib
+    a, b = _cl(a), _cl(b)
+    c = _cl(c) if c is not None else None
+    y = torch.empty_like(a, memory_format=torch.channels_last)
+    _lib.check(_lib.load().pp_add3_f16(_ptr(a), _ptr(b), _ptr(c), _ptr(y), a.numel(), _stream(a)))
+    return y
+
+
 def channel_mean(x: torch.Tensor) -> torch.Tensor:
     """(n, c, h, w) -> (n, c) mean over the pixels (the SE squeeze); HIP kernel on channels-last fp16, torch elsewhere."""
     n, c, h, w = x.shape
@@ -278,17 +291,20 @@ class FHourglass(nn.Module):
                 mods.append(FResidual(hg.hg[i][4]))
             self.levels.append(nn.ModuleList(mods))
 
-    def _level(self, i, x, coarse):
+    def _level(self, i, x, coarse, cache0=None):
         lv = self.levels[i]
         up1 = lv[0](x)
         low = lv[1](maxpool2(x))
         low = lv[4](low) if i == self.depth - 1 else self._level(i + 1, low, coarse)
         coarse.append(low)
+        if cache0 is not None:   # top level of stages 2..: up1 + up2 + cache in ONE pass (the conv runs without the extra read)
+            return add3(lv[3](upsample2(lv[2](low))), up1, cache0)
         return lv[3](upsample2(lv[2](low)), post=up1)  # up1 + act(conv(up2) + b): the add rides on the epilogue
 
-    def forward(self, x):
+    def forward(self, x, cache0=None):
+        """-> [top (+ cache0 when given), coarse levels...]"""
         coarse = []
-        top = self._level(0, x, coarse)
+        top = self._level(0, x, coarse, cache0)
         return [top] + coarse[::-1]
 
 
@@ -347,11 +363,11 @@ class FusedIMHN(nn.Module):
         x = torch.cat([x, d], dim=1)
         caches = None
         for t in range(self.S):
-            hg = self.hg[t](x)
-            if caches is not None:
-                hg = [a + c for a, c in zip(hg, caches)]
             last = t == self.S - 1
             scales = range(1) if last else range(self.K)  # the last stage's coarse heads feed nothing
+            hg = self.hg[t](x, None if caches is None else caches[0])   # scale 0 comes back with its cache added
+            if caches is not None:
+                hg = [hg[0]] + [hg[s] + caches[s] for s in scales if s > 0]
             feats = [self.feat[t][s](hg[s]) for s in scales]
             preds = [self.head[t][s](feats[s]) for s in scales]
             if last:

@@ -145,6 +145,8 @@ PP_API int pp_bias_act_f16(void *y, const void *bias, const void *residual, cons
                            float slope, int has_act, void *stream);
 PP_API int pp_maxpool2_f16(const void *x, void *y, long n, int h_out, int w_out, int channels, void *stream);
 PP_API int pp_upsample2_f16(const void *x, void *y, long n, int h_in, int w_in, int channels, void *stream);
+/* y = a + b (+ c) on fp16 tensors of n_elems elements (multiple of 8, 16-byte aligned), fp32 sum rounded once; c may be NULL. */
+PP_API int pp_add3_f16(const void *a, const void *b, const void *c, void *y, long n_elems, void *stream);
 /* SE squeeze (models/layers_transposed.py SELayer, AdaptiveAvgPool2d(1)): out[n][c] = mean over the h*w pixels of the NHWC fp16
  * activation x (n, hw, channels), fp32 accumulation.  partial_ws: DEVICE float[n][splits][channels] scratch; splits = number of
  * workgroups per image (pick n*splits >= ~1024).  channels % 8 == 0, channels <= 2048. */

@@ -25,6 +25,8 @@ def test_helper_kernels_match_torch():
             if post is not None:
                 ref = ref + post.float()
             assert torch.equal(y, ref.half()), (n, c, h, w, res is not None, act, post is not None)
+        assert torch.allclose(fm.add3(x, r, p).float(), x.float() + r.float() + p.float(), rtol=0, atol=4e-3)
+        assert torch.equal(fm.add3(x, r), x + r)
         sc = torch.rand(n, c, generator=g).cuda().half()
         assert torch.equal(fm.channel_scale(x, sc), x * sc[:, :, None, None])
         m = fm.channel_mean(x)
