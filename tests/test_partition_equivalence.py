@@ -1,0 +1,85 @@
+"""CPU: the lane-parallel formulation of libstdc++'s __unguarded_partition used by K_B (csrc/posepaf_kernels.hip,
+StdSortGE::partition_wave) against the sequential loop it replaces (bits/stl_algo.h, as restated in
+oracle/posepaf_oracle.c ls_unguarded_partition), with the reference's non-strict comparator a >= b
+(pafprocess.cpp:333-335).  Pure Python on small arrays with many ties, windows inside longer arrays (so that the unguarded
+scans can leave the window), both scans allowed to run off the array (flagged oob)."""
+import random
+
+import pytest
+
+
+def sequential(keys, first, last, pivot):
+    """bits/stl_algo.h __unguarded_partition with comp(a, b) = a >= b; scans stop at the array bounds (oob)."""
+    a = list(keys)
+    n, pv, oob = len(a), a[pivot], False
+    while True:
+        while True:
+            if first >= n:
+                oob = True
+                break
+            if not (a[first] >= pv):
+                break
+            first += 1
+        last -= 1
+        while True:
+            if last < 0:
+                oob = True
+                break
+            if not (pv >= a[last]):
+                break
+            last -= 1
+        if not (first < last):
+            return a, first, oob
+        a[first], a[last] = a[last], a[first]
+        first += 1
+
+
+def stopper_lists(keys, first, last, pivot):
+    """What partition_wave computes: left stoppers (< pivot) upwards, right stoppers (> pivot) downwards, k swaps, the cut."""
+    a = list(keys)
+    n, pv, oob = len(a), a[pivot], False
+    L = [i for i in range(first, last) if a[i] < pv]
+    R = [j for j in range(last - 1, first - 1, -1) if a[j] > pv]
+    k = sum(1 for i in range(min(len(L), len(R))) if L[i] < R[i])
+    for i in range(k):
+        a[L[i]], a[R[i]] = a[R[i]], a[L[i]]
+    if k >= 1:
+        cut = L[k] if (k < len(L) and L[k] < R[k - 1]) else R[k - 1]
+    elif L:
+        cut = L[0]
+    else:
+        beyond = [i for i in range(last, n) if a[i] < pv]
+        cut = beyond[0] if beyond else n
+        oob |= not beyond
+    if k == 0 and not R:
+        oob |= not any(a[j] > pv for j in range(first - 1, -1, -1))
+    return a, cut, oob
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_stopper_list_partition_equals_sequential_scan(seed):
+    rng = random.Random(seed)
+    for _ in range(1500):
+        n = rng.randint(3, 90)
+        levels = rng.choice([2, 3, 5, 40])              # few distinct keys -> many exact ties
+        keys = [float(rng.randint(0, levels)) for _ in range(n)]
+        pivot = rng.randint(0, n - 2)
+        first = pivot + 1                                # std::__unguarded_partition_pivot: pivot sits just below the range
+        last = rng.randint(first, n)
+        want = sequential(keys, first, last, pivot)
+        got = stopper_lists(keys, first, last, pivot)
+        assert got == want, (keys, first, last, pivot)
+
+
+def test_windows_where_a_scan_leaves_the_range():
+    # every element of the window >= pivot: the left scan runs on into the neighbouring elements
+    keys = [5.0, 7.0, 7.0, 9.0, 6.0, 1.0]
+    assert stopper_lists(keys, 1, 4, 0) == sequential(keys, 1, 4, 0)
+    # nothing smaller anywhere to the right: off the array
+    keys = [5.0, 7.0, 7.0, 9.0]
+    a, cut, oob = stopper_lists(keys, 1, 4, 0)
+    assert (a, cut, oob) == sequential(keys, 1, 4, 0) and oob and cut == 4
+    # nothing greater in the window or below it: the right scan passes the pivot and leaves the array
+    keys = [5.0, 5.0, 3.0, 5.0]
+    assert stopper_lists(keys, 1, 4, 0) == sequential(keys, 1, 4, 0)
+    assert stopper_lists(keys, 1, 4, 0)[2]
