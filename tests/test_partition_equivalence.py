@@ -83,3 +83,52 @@ def test_windows_where_a_scan_leaves_the_range():
     keys = [5.0, 5.0, 3.0, 5.0]
     assert stopper_lists(keys, 1, 4, 0) == sequential(keys, 1, 4, 0)
     assert stopper_lists(keys, 1, 4, 0)[2]
+
+
+def final_insertion_sort(keys):
+    """bits/stl_algo.h __final_insertion_sort with comp(a, b) = a >= b on (key, position) pairs: guarded insertion sort of
+    the first 16, __unguarded_linear_insert for the rest (runs off the front -> oob)."""
+    a = [(k, i) for i, k in enumerate(keys)]
+    n, oob = len(a), False
+
+    def linear_insert(last, guarded_first):
+        nonlocal oob
+        val = a[last]
+        nxt = last - 1
+        while True:
+            if nxt < 0:
+                oob = True
+                break
+            if not (val[0] >= a[nxt][0]):
+                break
+            a[nxt + 1] = a[nxt]
+            nxt -= 1
+        a[nxt + 1] = val
+
+    for i in range(1, min(n, 16)):              # __insertion_sort(first, first + 16)
+        if a[i][0] >= a[0][0]:                  # comp(i, first): move_backward, no scan
+            a[0:i + 1] = [a[i]] + a[0:i]
+        else:
+            linear_insert(i, True)
+    for i in range(16, n):                      # __unguarded_insertion_sort
+        linear_insert(i, False)
+    return a, oob
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_final_insertion_sort_closed_form(seed):
+    """K_B does not emulate the final insertion sort: the result is 'descending key, ties in REVERSE of their position in the
+    array it starts from', and the unguarded insert of element p >= 16 leaves the array iff nothing strictly greater precedes it."""
+    rng = random.Random(100 + seed)
+    for _ in range(1500):
+        n = rng.randint(1, 70)
+        levels = rng.choice([1, 2, 4, 30])
+        keys = [float(rng.randint(0, levels)) for _ in range(n)]
+        got, oob = final_insertion_sort(keys)
+        want_oob = any(p >= 16 and all(not (keys[q] > keys[p]) for q in range(p)) for p in range(n))
+        assert oob == want_oob, keys
+        if not oob:
+            rank = [sum(1 for q in range(n) if keys[q] > keys[p]) + sum(1 for q in range(p + 1, n) if keys[q] == keys[p])
+                    for p in range(n)]
+            assert sorted(rank) == list(range(n))
+            assert [pos for _, pos in got] == [p for _, p in sorted(zip(rank, range(n)))], keys
