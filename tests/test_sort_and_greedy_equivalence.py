@@ -132,3 +132,49 @@ def test_final_insertion_sort_closed_form(seed):
                     for p in range(n)]
             assert sorted(rank) == list(range(n))
             assert [pos for _, pos in got] == [p for _, p in sorted(zip(rank, range(n)))], keys
+
+
+def greedy_sequential(cands):
+    """pafprocess.cpp:113-129: candidates in sorted order; take one if neither end point is used yet."""
+    used_a, used_b, out = set(), set(), []
+    for rank, (a, b) in enumerate(cands):
+        if a not in used_a and b not in used_b:
+            used_a.add(a)
+            used_b.add(b)
+            out.append(rank)
+    return out
+
+
+def greedy_locally_dominant(cands):
+    """K_B: repeat { every live candidate whose rank is the lowest among the live candidates sharing its a AND among those
+    sharing its b is accepted; its end points retire; candidates touching a retired end point die }."""
+    state = [0] * len(cands)           # 0 live, 1 accepted, 2 dead
+    used_a, used_b = set(), set()
+    for _ in range(len(cands) + 1):
+        min_a, min_b, live = {}, {}, False
+        for r, (a, b) in enumerate(cands):
+            if state[r] == 0:
+                if a in used_a or b in used_b:
+                    state[r] = 2
+                else:
+                    min_a[a] = min(min_a.get(a, r), r)
+                    min_b[b] = min(min_b.get(b, r), r)
+                    live = True
+        if not live:
+            break
+        for r, (a, b) in enumerate(cands):
+            if state[r] == 0 and min_a[a] == r and min_b[b] == r:
+                state[r] = 1
+                used_a.add(a)
+                used_b.add(b)
+    return [r for r, s in enumerate(state) if s == 1]
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_locally_dominant_greedy_equals_sequential_greedy(seed):
+    rng = random.Random(500 + seed)
+    for _ in range(2000):
+        na, nb = rng.randint(1, 9), rng.randint(1, 9)
+        pairs = [(a, b) for a in range(na) for b in range(nb) if rng.random() < 0.6]
+        rng.shuffle(pairs)             # position in the list = rank in the reference's sorted order (ranks are distinct)
+        assert greedy_locally_dominant(pairs) == greedy_sequential(pairs)
