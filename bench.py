@@ -143,7 +143,7 @@ def bench_multiscale(a, world, rank, dev, dist, backend, model, post, images):
     recs = records_to_numpy(rec)
     if rank == 0:
         print(json.dumps({
-            "metric": "end-to-end images/sec at 512x512, multi-scale", "value": world * B * a.steps / dt, "unit": "images/sec",
+            "metric": "end-to-end images/sec at 512×512, multi-scale", "value": world * B * a.steps / dt, "unit": "images/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16",
             "data": "synthetic (random-init IMHN weights, random uint8 images, the same synthetic people injected at every scale)",
@@ -277,7 +277,7 @@ def main():
                         "shapes_miopen_plus_epilogue": sum(1 for v in ch.values() if v < 0)}
     if rank == 0:
         out = {
-            "metric": "end-to-end images/sec at 512x512", "value": world * B * a.steps / dt, "unit": "images/sec",
+            "metric": "end-to-end images/sec at 512×512", "value": world * B * a.steps / dt, "unit": "images/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
             "data": "synthetic (random-init IMHN weights, random uint8 images, synthetic GT-style pose scenes injected "
