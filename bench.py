@@ -2,24 +2,35 @@
 """bench.py -- end-to-end images/sec at 512x512 (BASELINE.json's metric) on N GPUs of one node.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the whole hot path over one batch of B synthetic 512x512 images per GPU, inputs already
-resident in HBM: uint8 pre-processing + flip -> 4-stage IMHN forward on (2B, 512, 512, 3) in fp16 ->
-K_A heat-map NMS/refine -> K_B limb line-integral scoring + matching -> K_C person assembly -> (N > 1) RCCL
-all-gather of the per-image records.  Images shard across ranks (weak scaling: B per GPU); there is no other
-collective on the path.
+With --gpus N > 1 and no WORLD_SIZE in the environment the script LAUNCHES ITS OWN RANKS (one process per GPU through
+`python -m torch.distributed.run`, rendezvous on 127.0.0.1) before anything touches the GPU, waits for them and exits with
+their return code; under an outer torchrun (WORLD_SIZE set) it is one of the ranks.  Rank 0 prints ONE JSON line.
 
-A randomly initialised network emits no peaks, so the post-processing load comes from synthetic ground-truth
-style scenes (posepaf/synth.py) ADDED to the (down-scaled) network output: the forward is fully live and the
-kernels see realistic peak/limb counts.  Nothing is skipped or cached inside the timed region.
+One "step" = one pass of the whole hot path over one batch of B synthetic 512x512 images per GPU:
+pinned-host -> HBM upload of the uint8 batch (copy stream, double-buffered: the upload of batch k+1 overlaps the compute
+of batch k; utils/parse_skeletons.py:73) -> uint8 pre-processing + flip -> 4-stage IMHN forward on (2B, 512, 512, 3) in
+fp16 -> K_A heat-map NMS/refine -> K_BC limb line-integral scoring + matching + person assembly -> (N > 1) RCCL
+all-gather of the per-image records.  Images shard across ranks (weak scaling: B per GPU); no other collective.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant hand-written kernel (k_limb_connect), timed with
-HIP events on the launch stream; `cpu_baseline` is the oracle (plain-C port of the reference path) on one host core.
+A randomly initialised network emits no peaks, so the post-processing load comes from synthetic ground-truth style scenes
+(posepaf/synth.py) ADDED to the (down-scaled) network output: the forward is fully live and the kernels see realistic
+peak/limb counts.  Nothing is skipped or cached inside the timed region.
+
+`roofline` is for the longest hand-written post-processing kernel (HIP events on the launch stream) and carries the
+chain-level fraction too; `roofline_forward` prices the step against the dense fp16 MFMA peak with the FLOPs the
+inference model actually executes (tools/count_flops.py); `cpu_baseline` is the oracle (plain-C port of the reference
+path) on all host cores, one image per core, with a per-stage single-core split.
+
+POSEPAF_BENCH_STUB=1 replaces the GPU engine by a CPU stub (records filled by numpy) so that the control flow --
+self-launch, process group, sharding, per-step exchange, MAX-over-ranks timing, status check, the JSON line -- can be
+exercised on a machine without GPUs (tests/test_bench_control_flow.py, gloo, world size 2).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,25 +40,19 @@ for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-# one MIOpen user database per rank: eight processes tuning the same shapes must not serialise on one file lock
-_rank = os.environ.get("LOCAL_RANK", "0")
-os.environ.setdefault("MIOPEN_USER_DB_PATH", f"/tmp/posepaf_miopen_db_rank{_rank}")
-os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", f"/tmp/posepaf_miopen_cache_rank{_rank}")
-os.makedirs(os.environ["MIOPEN_USER_DB_PATH"], exist_ok=True)
-os.makedirs(os.environ["MIOPEN_CUSTOM_CACHE_DIR"], exist_ok=True)
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 IMG = 512
 FEAT = IMG // 4
 SCENE_PEOPLE = (1, 2, 3, 4, 5, 6, 8, 10, 12, 15, 20, 30, 2, 4, 6, 3)   # people per synthetic scene (mean 8.2)
 HBM_PEAK_GBS = 8000.0                                                   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F16_PEAK_TFLOPS = 2500.0                                           # MI355X_MICROARCH.md: dense fp16/bf16 MFMA peak
-FLOP_PER_IMAGE = 2 * 529.4e9                                            # 529.4 GFLOP / forward, x2 flip
+FLOP_PER_FORWARD_REFERENCE = 529.39e9                                   # the reference module, 512x512
+FLOP_PER_FORWARD_EXECUTED = 512.18e9                                    # tools/count_flops.py: the inference model (the last
+#                                                                         stage's unused coarse heads are not computed)
+FLOP_PER_IMAGE = 2 * FLOP_PER_FORWARD_EXECUTED                          # flip: two forwards per image
+ST_DEFINED, ST_SORT_UNDEFINED = 0x3F, 8                                 # include/posepaf.h:53-59
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -55,192 +60,377 @@ def parse():
     ap.add_argument("--batch", type=int, default=int(os.environ.get("POSEPAF_BENCH_BATCH", "64")),
                     help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="bound on the CPU baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=16.0, help="bound on the CPU baseline leg (all parts together)")
+    ap.add_argument("--cpu-cores", type=int, default=0, help="worker processes of the CPU baseline (0 = all this process may use, <= 16)")
     ap.add_argument("--postproc-only", action="store_true", help="time only K_A..K_C (profiling aid)")
     ap.add_argument("--plain-model", action="store_true", help="unfused nn.Module forward instead of the fused one")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--no-ingest", action="store_true", help="leave the host->HBM upload out of the step (round-1 form)")
     ap.add_argument("--multiscale", action="store_true",
                     help="BASELINE configs[4]: original path, scale search {0.5, 1.0, 1.5} x 512 + flip, float64 accumulation")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
-def build_scenes(batch, dtype=np.float16):
+# ------------------------------------------------------------------------------------------------ self-launch
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(a, argv):
+    """--gpus N > 1 from a plain shell: start N ranks as CHILD processes (never exec: nothing here has touched the GPU, and
+    nothing will in this parent), forward their output, return their exit code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def build_scenes(batch, dtype=None):
+    import numpy as np
     from posepaf import synth
+    dtype = dtype or np.float16
     uniq = [synth.make_net_output(p, 9000 + i, dtype=dtype) for i, p in enumerate(SCENE_PEOPLE)]
     return np.stack([uniq[i % len(uniq)] for i in range(batch)]), uniq
 
 
-def cpu_baseline(uniq_scenes, seconds):
-    """Oracle (plain-C restatement of flip-average + heatmap_nms + x4 limb upsample + process_paf) on ONE core,
-    same synthetic scenes, bounded wall time.  The network forward is NOT included (fp32 CPU forward of the
-    reference module: ~6.5 s per image on 8 threads)."""
+_W_ORC, _W_SCENES = None, None
+
+
+def _cpu_worker_init(scenes):
+    global _W_ORC, _W_SCENES
+    os.environ["OMP_NUM_THREADS"] = "1"
     from oracle.oracle import Oracle
-    orc = Oracle()
+    _W_ORC = Oracle()
+    _W_SCENES = scenes
+
+
+def _cpu_worker_run(args):
+    """one worker = one core: whole post-processing of one image at a time until the deadline"""
+    start, deadline = args
+    n, k = 0, start
+    while time.time() < deadline:
+        _W_ORC.pipeline(_W_SCENES[k % len(_W_SCENES)], IMG)
+        n += 1
+        k += 1
+    return n
+
+
+def _time_loop(fn, seconds):
     n, t0 = 0, time.perf_counter()
     while True:
-        for s in uniq_scenes:
-            orc.pipeline(s, IMG)
-            n += 1
-        if time.perf_counter() - t0 > seconds:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "images/sec", "cores": 1, "kind": "port",
-            "sample": f"{n} images ({len(uniq_scenes)} scenes of {min(SCENE_PEOPLE)}-{max(SCENE_PEOPLE)} people, cycled) "
-                      f"in {dt:.1f} s; post-processing only (flip-average, NMS+refine, x4 limb upsample, process_paf); "
-                      "network forward excluded"}
+        fn(n)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > seconds and n >= 3:
+            return n / dt, n
 
 
-def bench_multiscale(a, world, rank, dev, dist, backend, model, post, images):
-    """configs[4]: predict's scale search (0.5, 1.0, 1.5) with flip, per-scale maps up-sampled, resized to the image and
-    accumulated in float64 in HBM, then find_peaks + the Python-twin matching at image resolution."""
-    from posepaf import synth
-    from posepaf._lib import RECORD_BYTES
-    from posepaf.api import records_to_numpy
-    from posepaf.original_path import OriginalPathProcessor, resize_images_u8
-    from posepaf.pipeline import preprocess_batch
-    B = a.batch
-    mult = (0.5, 1.0, 1.5)
-    sizes = [(64, 64, 0.5), (128, 128, 1.0), (192, 192, 1.5)]
-    proc = OriginalPathProcessor(post, IMG, IMG, B)
-    uniq = [synth.make_scene_at_scales(p, 9100 + i, sizes)[0] for i, p in enumerate(SCENE_PEOPLE)]
-    inject = [torch.from_numpy(np.stack([uniq[i % len(uniq)][k] for i in range(B)])).to(dev) for k in range(len(sizes))]
-    scale = torch.tensor(1e-3, dtype=torch.float16, device=dev)
-    gdev = dev if backend == "nccl" else torch.device("cpu")
-    gathered = torch.empty(world * B * RECORD_BYTES, dtype=torch.uint8, device=gdev) if world > 1 else None
+def cpu_baseline(seconds, cores=0):
+    """The oracle -- the plain-C restatement of the reference's CPU path, pinned bit-exact against the reference's own
+    compiled C++ and Python outputs (tests/test_oracle_*.py) -- timed on this machine's host cores, SURVEY.md 8(d):
+      value      : whole post-processing (flip-average, heatmap_nms with x4 patch refinement, x4 limb upsample, process_paf),
+                   one image per core on all cores, bench.py's scene mix;
+      stages     : images/sec of each stage on ONE core, incl. the pure-Python rule set (find_connections + find_humans,
+                   what the reference runs without --run_cpp) as its C port.
+    The network forward is not part of it (fp32 CPU forward of the reference module: ~6.5 s per image on 8 threads,
+    SURVEY.md section 6)."""
+    import multiprocessing as mp
+    import numpy as np
+    from oracle.oracle import Oracle
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = cores or min(avail, 16)
+    orc = Oracle()
+    _, uniq = build_scenes(len(SCENE_PEOPLE))
+    nu = len(uniq)
+    part = seconds / 8.0
+    # ---- single-core stage split
+    single, _ = _time_loop(lambda i: orc.pipeline(uniq[i % nu], IMG), part)
+    flips = [orc.flip_average(s) for s in uniq]
+    st_flip, _ = _time_loop(lambda i: orc.flip_average(uniq[i % nu]), part / 2)
+    st_nms, _ = _time_loop(lambda i: orc.heatmap_nms(flips[i % nu][0]), part)
+    jls = [orc.heatmap_nms(f[0])[0] for f in flips]
+    st_up, _ = _time_loop(lambda i: orc.upsample4_hwc(flips[i % nu][1]), part / 2)
+    mid = [5, 7, 9, 11]                                    # 6, 10, 15 and 30 people (mean 15): four 31.5 MB up-sampled maps
+    ups = [orc.upsample4_hwc(flips[k][1]) for k in mid]
+    st_cpp, _ = _time_loop(lambda i: orc.process_paf(jls[mid[i % 4]][None], ups[i % 4], IMG), part)
+    st_py, _ = _time_loop(lambda i: orc.py_find_humans(jls[mid[i % 4]], ups[i % 4], IMG), part)
+    del ups
+    # ---- all cores, one image per core
+    par_seconds = max(2.0, seconds - 5.5 * part)
+    ctx = mp.get_context("spawn")      # never fork a process that holds a HIP context
+    with ctx.Pool(cores, initializer=_cpu_worker_init, initargs=(uniq,)) as pool:
+        pool.map(_cpu_worker_run, [(i, time.time() + 0.2) for i in range(cores)])          # start-up + first touch
+        t0 = time.time()
+        counts = pool.map(_cpu_worker_run, [(3 * i, t0 + par_seconds) for i in range(cores)])
+        dt = time.time() - t0
+    n = int(np.sum(counts))
+    return {"value": n / dt, "unit": "images/sec", "cores": cores, "host_cores_available": avail, "kind": "port",
+            "sample": f"{n} images ({nu} scenes of {min(SCENE_PEOPLE)}-{max(SCENE_PEOPLE)} people, cycled) in {dt:.1f} s on "
+                      f"{cores} worker processes, one image per core; post-processing only (flip-average, NMS + x4 patch "
+                      "refinement, x4 limb upsample, process_paf); network forward excluded",
+            "single_core": {"value": single, "unit": "images/sec"},
+            "stages_single_core_images_per_sec": {
+                "flip_average": st_flip, "heatmap_nms": st_nms, "limb_upsample_x4": st_up,
+                "process_paf_cpp_rules": st_cpp, "find_connections+find_humans_python_rules_as_C": st_py,
+                "matching_stage_scenes": "6, 10, 15 and 30 people"},
+            "note": "the Python-rule figure is the C port of utils/parse_skeletons.py:324-600; the reference's interpreted "
+                    "NumPy version of the same stage runs at 5.2 FPS on the authors' machine (README.md:86)"}
 
-    def step():
+
+# ------------------------------------------------------------------------------------------------ engines
+class StubEngine:
+    """CPU stand-in for the GPU engine (control-flow tests): records with recognisable content, no HIP."""
+
+    name = "stub"
+
+    def __init__(self, a, rank, world):
+        import numpy as np
+        import torch
+        from posepaf._lib import RECORD_BYTES, RECORD_DTYPE
+        self.torch, self.B, self.rank = torch, a.batch, rank
+        rec = np.zeros(a.batch, RECORD_DTYPE)
+        rec["n_humans"] = 1 + rank
+        rec["n_peaks"] = 100 * rank + np.arange(a.batch)
+        rec["status"] = int(os.environ.get("POSEPAF_BENCH_STUB_STATUS", "0"), 0)
+        self.rec = torch.from_numpy(rec.view(np.uint8).copy())
+        assert self.rec.numel() == a.batch * RECORD_BYTES
+        self.gather_device = torch.device("cpu")
+        self.steps_run = 0
+
+    def step(self):
+        self.steps_run += 1
+        time.sleep(0.002)
+        return self.rec
+
+    def sync(self):
+        pass
+
+    def extras(self, a, dt, world):
+        return {"stub": True, "steps_run": self.steps_run}
+
+
+class GpuEngine:
+    name = "gpu"
+
+    def __init__(self, a, rank, world, local, backend):
+        import numpy as np
+        import torch
+        assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU path)"
+        from posepaf.api import PosePostProcessor
+        from posepaf.fused_model import build_inference_model
+        from posepaf.pipeline import PosePipeline
+        self.torch, self.a, self.B = torch, a, a.batch
+        local = local % torch.cuda.device_count()
+        torch.cuda.set_device(local)
+        self.dev = dev = torch.device("cuda", local)
+        self.local = local
+        # MIOpen exhaustive find (miopenFindConvolutionForwardAlgorithm) per conv shape: +30 % over the default heuristic
+        if os.environ.get("POSEPAF_CUDNN_BENCHMARK", "1") == "1":
+            torch.backends.cudnn.benchmark = True
+        self.gather_device = dev if backend == "nccl" else torch.device("cpu")
+        B = a.batch
+        self.post = PosePostProcessor(max_batch=B, max_h=FEAT if not a.multiscale else 192, max_w=FEAT if not a.multiscale else 192,
+                                      max_peaks_per_part=64, device=local)
+        scenes_np, self.uniq = build_scenes(B)
+        self.inject = torch.from_numpy(scenes_np).to(dev)                                   # (B,2,50,128,128) fp16
+        # host side of the ingest: two different pinned batches, uploaded alternately
+        g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+        self.host = [torch.randint(0, 256, (B, IMG, IMG, 3), dtype=torch.uint8, generator=g).pin_memory() for _ in range(2)]
+        self.staging = [torch.empty((B, IMG, IMG, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.copy_stream = torch.cuda.Stream(device=dev)
+        self.uploaded = [torch.cuda.Event() for _ in range(2)]
+        self.consumed = [torch.cuda.Event() for _ in range(2)]
+        self.static_images = self.host[0].to(dev)
+        self.k = 0
+        self.model = None if a.postproc_only else build_inference_model(dev, fused=not a.plain_model)
+        self.pipe = PosePipeline(self.model, self.post, dtype=torch.float16, flip=True)
+        self.scale = torch.tensor(1e-3, dtype=torch.float16, device=dev)
+        self.graph, self.static_rec = None, None
+        if a.multiscale:
+            self._init_multiscale()
+        elif not a.no_graph:
+            # HIP graph of the whole per-batch path (forward + K_A / K_BC): ~1000 launches replayed as one
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(2):
+                    self._body()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph), torch.no_grad():
+                self.static_rec = self._body()
+        if not a.no_ingest:
+            self._upload(0)
+
+    # -- ingest: batch k is uploaded into staging[k % 2] on the copy stream while batch k-1 computes
+    def _upload(self, k):
+        torch = self.torch
+        s = k % 2
+        with torch.cuda.stream(self.copy_stream):
+            self.copy_stream.wait_event(self.consumed[s])          # the compute stream is done reading this buffer
+            self.staging[s].copy_(self.host[k % 2], non_blocking=True)
+            self.uploaded[s].record(self.copy_stream)
+
+    def _body(self):
+        torch = self.torch
+        if self.a.postproc_only:
+            return self.post.process_async(self.inject, IMG, True)
+        maps = self.pipe.forward_maps(self.static_images)
+        maps = torch.addcmul(self.inject, maps, self.scale)
+        return self.post.process_async(maps, IMG, True)
+
+    def _init_multiscale(self):
+        from posepaf import synth
+        import numpy as np
+        from posepaf.original_path import OriginalPathProcessor
+        torch = self.torch
+        self.ms_sizes = [(64, 64, 0.5), (128, 128, 1.0), (192, 192, 1.5)]
+        self.proc = OriginalPathProcessor(self.post, IMG, IMG, self.B)
+        uniq = [synth.make_scene_at_scales(p, 9100 + i, self.ms_sizes)[0] for i, p in enumerate(SCENE_PEOPLE)]
+        self.ms_inject = [torch.from_numpy(np.stack([uniq[i % len(uniq)][k] for i in range(self.B)])).to(self.dev)
+                          for k in range(len(self.ms_sizes))]
+
+    def _body_multiscale(self):
+        from posepaf.original_path import resize_images_u8
+        from posepaf.pipeline import preprocess_batch
+        torch = self.torch
+        self.proc.reset()
+        for k, (h, w, sc) in enumerate(self.ms_sizes):
+            scaled = resize_images_u8(self.static_images, sc)
+            x = preprocess_batch(scaled, True, torch.float16)
+            maps = self.model(x).view(self.B, 2, 50, h, w)
+            maps = torch.addcmul(self.ms_inject[k], maps, self.scale)
+            self.proc.accumulate(maps, 0, 0, len(self.ms_sizes))
+        return self.proc.finish(self.B)
+
+    def step(self):
+        torch = self.torch
+        cur = torch.cuda.current_stream()
+        if not self.a.no_ingest:
+            s = self.k % 2
+            cur.wait_event(self.uploaded[s])                       # batch k has landed in HBM
+            self.static_images.copy_(self.staging[s], non_blocking=True)   # into the graph's input buffer (HBM -> HBM)
+            self.consumed[s].record(cur)
+            self._upload(self.k + 1)                               # next batch rides under this step's compute
+            self.k += 1
+        if self.a.multiscale:
+            with torch.no_grad():
+                return self._body_multiscale()
+        if self.graph is not None:
+            self.graph.replay()
+            return self.static_rec
         with torch.no_grad():
-            proc.reset()
-            for k, sc in enumerate(mult):
-                scaled = resize_images_u8(images, sc)
-                x = preprocess_batch(scaled, True, torch.float16)
-                maps = model(x).view(B, 2, 50, sizes[k][0], sizes[k][1])
-                maps = torch.addcmul(inject[k], maps, scale)
-                proc.accumulate(maps, 0, 0, len(mult))
-            rec = proc.finish(B)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, rec if backend == "nccl" else rec.cpu())
-        return rec
+            return self._body()
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def sync(self):
+        self.torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        rec = step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        rec = step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=gdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    recs = records_to_numpy(rec)
-    if rank == 0:
-        print(json.dumps({
-            "metric": "end-to-end images/sec at 512×512, multi-scale", "value": world * B * a.steps / dt, "unit": "images/sec",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f16",
-            "data": "synthetic (random-init IMHN weights, random uint8 images, the same synthetic people injected at every scale)",
-            "config": {"workload": "configs[4]: original path, scales {0.5,1.0,1.5} x 512 + flip, float64 accumulation at image "
-                                   "resolution in HBM, find_peaks + Python-twin matching", "images_per_gpu_per_step": B,
-                       "people_per_scene": list(SCENE_PEOPLE), "parallelism": f"image-sharded x{world}"},
-            "humans_found_in_batch": int(recs["n_humans"].sum()), "status_or": int(np.bitwise_or.reduce(recs["status"]))}), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    def extras(self, a, dt, world):
+        """roofline of the hand-written kernels (HIP events on the launch stream) + forward roofline"""
+        B = a.batch
+        out = {}
+        if a.multiscale:
+            return out
+        ms = self.post.time_kernels(self.inject, IMG, True, iters=20)
+        # algorithmic bytes per launch (DESIGN.md section 3): every flip sample of every channel the kernel consumes, fp16, once
+        alg = {"k_heat_peaks": B * 18 * 2 * FEAT * FEAT * 2, "k_limb_connect": B * 30 * 2 * FEAT * FEAT * 2,
+               "k_assemble": B * 40960}                       # peaks + connections + record of one image: <= 40 KB
+        dom = max(alg, key=lambda k: ms[k])
+        chain_bytes = sum(alg.values())
+        achieved = alg[dom] / (ms[dom] * 1e-3) / 1e9
+        chain = chain_bytes / (ms["chain"] * 1e-3) / 1e9
+        traffic, src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(dom, {}).get(f"batch{B}")
+                src = "profiles/r02_pmc_traffic.json (rocprofv3 --pmc passes of tools/pmc_traffic.py on this build; not re-measured in this run)"
+            except Exception:
+                traffic = None
+        out["kernel_ms"] = ms
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
+                           "algorithmic_bytes_per_launch": alg[dom],
+                           "chain": {"kernels": sorted(alg), "ms": ms["chain"],
+                                     "algorithmic_bytes": chain_bytes, "achieved": chain, "frac": chain / HBM_PEAK_GBS}}
+        if not a.postproc_only:
+            tf = B * a.steps * FLOP_PER_IMAGE / dt / 1e12
+            out["forward_tflops_per_gpu"] = tf
+            out["roofline_forward"] = {
+                "bound": "mfma", "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F16_PEAK_TFLOPS,
+                "flop_per_forward": FLOP_PER_FORWARD_EXECUTED,
+                "note": "whole step time (ingest + forward + pre/post-processing) against the dense fp16 MFMA peak; FLOPs are "
+                        "those the inference model executes (512.18 GFLOP per 512x512 forward, tools/count_flops.py), not the "
+                        "reference module's 529.39 (its last stage's coarse heads are computed and discarded)"}
+            if not a.plain_model:
+                from posepaf.fused_model import conv_choices
+                ch = conv_choices()
+                out["conv_layers"] = {"shapes_own_kernel": sum(1 for v in ch.values() if v >= 100),
+                                      "shapes_ck_template_kernel": sum(1 for v in ch.values() if 0 <= v < 100),
+                                      "shapes_miopen_plus_epilogue": sum(1 for v in ch.values() if v < 0)}
+        return out
 
 
-def main():
-    a = parse()
+# ------------------------------------------------------------------------------------------------ main
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    a = parse(argv)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(a, argv)            # before ANY GPU call in this process
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU path)"
-    backend = os.environ.get("POSEPAF_DIST_BACKEND", "nccl")   # "gloo": rehearsal of the N>1 control flow on one GPU
-    local = local % torch.cuda.device_count()
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    # MIOpen exhaustive find (miopenFindConvolutionForwardAlgorithm) per conv shape: +30 % over the default heuristic
-    if os.environ.get("POSEPAF_CUDNN_BENCHMARK", "1") == "1":
-        torch.backends.cudnn.benchmark = True
+    if world != a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        return 2
+    stub = os.environ.get("POSEPAF_BENCH_STUB", "0") == "1"
+    backend = os.environ.get("POSEPAF_DIST_BACKEND", "gloo" if stub else "nccl")   # "gloo": control-flow rehearsal
+
+    # one MIOpen user database per rank: eight processes tuning the same shapes must not serialise on one file lock
+    os.environ.setdefault("MIOPEN_USER_DB_PATH", f"/tmp/posepaf_miopen_db_rank{local}")
+    os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", f"/tmp/posepaf_miopen_cache_rank{local}")
+    os.makedirs(os.environ["MIOPEN_USER_DB_PATH"], exist_ok=True)
+    os.makedirs(os.environ["MIOPEN_CUSTOM_CACHE_DIR"], exist_ok=True)
+
+    import numpy as np
+    import torch
+    from posepaf._lib import RECORD_BYTES
+    from posepaf.api import records_to_numpy
+
     dist = None
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+            ndev = torch.cuda.device_count()          # does not initialise the GPU
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local % max(ndev, 1)))   # RCCL over xGMI
         else:
             dist.init_process_group(backend)
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
-    from posepaf._lib import RECORD_BYTES
-    from posepaf.api import PosePostProcessor, records_to_numpy
-    from posepaf.pipeline import PosePipeline
-    from posepaf.fused_model import build_inference_model
-
+    eng = StubEngine(a, rank, world) if stub else GpuEngine(a, rank, world, local, backend)
     B = a.batch
-    post = PosePostProcessor(max_batch=B, max_h=FEAT, max_w=FEAT, max_peaks_per_part=64, device=local)
-    scenes_np, uniq = build_scenes(B)
-    inject = torch.from_numpy(scenes_np).to(dev)                                   # (B,2,50,128,128) fp16
-    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    images = torch.randint(0, 256, (B, IMG, IMG, 3), dtype=torch.uint8, generator=g).to(dev)
-
-    model = None
-    if not a.postproc_only:
-        model = build_inference_model(dev, fused=not a.plain_model)
-    pipe = PosePipeline(model, post, dtype=torch.float16, flip=True)
-    gdev = dev if backend == "nccl" else torch.device("cpu")
+    gdev = eng.gather_device
     gathered = torch.empty(world * B * RECORD_BYTES, dtype=torch.uint8, device=gdev) if world > 1 else None
 
-    scale = torch.tensor(1e-3, dtype=torch.float16, device=dev)
-    static_images = images.clone()
-
-    if a.multiscale:
-        return bench_multiscale(a, world, rank, dev, dist, backend, model, post, images)
-
-    def body():
-        if a.postproc_only:
-            return post.process_async(inject, IMG, True)
-        maps = pipe.forward_maps(static_images)
-        maps = torch.addcmul(inject, maps, scale)
-        return post.process_async(maps, IMG, True)
-
-    graph, static_rec = None, None
-    if not a.no_graph:
-        # HIP graph of the whole per-batch path (forward + K_A/K_B/K_C): ~1000 launches replayed as one
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(2):
-                body()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph), torch.no_grad():
-            static_rec = body()
-
     def step():
-        if graph is not None:
-            static_images.copy_(images, non_blocking=True)   # a fresh batch lands in the graph's input buffer
-            graph.replay()
-            rec = static_rec
-        else:
-            with torch.no_grad():
-                rec = body()
+        rec = eng.step()
         if world > 1:   # the path's only exchange: fixed-size per-image records, one collective per batch
-            dist.all_gather_into_tensor(gathered, rec if backend == "nccl" else rec.cpu())
+            dist.all_gather_into_tensor(gathered, rec if rec.device == gdev else rec.to(gdev))
         return rec
 
     def fence():
-        torch.cuda.synchronize()
+        eng.sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        eng.sync()
 
     for _ in range(a.warmup):
         rec = step()
@@ -254,57 +444,53 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=gdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    # every rank checks its own records; the verdicts are combined so that rank 0's line and every exit code agree
     recs = records_to_numpy(rec)
+    status_or = int(np.bitwise_or.reduce(recs["status"].astype(np.uint32)))
+    humans = int(recs["n_humans"].sum())
+    if world > 1:
+        allrec = gathered.cpu().numpy().view(recs.dtype)
+        status_or = int(np.bitwise_or.reduce(allrec["status"].astype(np.uint32)))
+        humans = int(allrec["n_humans"].sum())
+    allowed = ST_SORT_UNDEFINED | (32 if a.multiscale else 0)
+    bad_status = bool(status_or & ~ST_DEFINED) or bool(status_or & ~allowed)
 
-    # ---- roofline of the dominant hand-written kernel, HIP events on the launch stream
-    ms = post.time_kernels(inject, IMG, True, iters=20)
-    alg_bytes = {"k_heat_peaks": B * 18 * 2 * FEAT * FEAT * 2, "k_limb_connect": B * 30 * 2 * FEAT * FEAT * 2}
-    dom = "k_limb_connect"
-    achieved = alg_bytes[dom] / (ms[dom] * 1e-3) / 1e9
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(pmc):
-        try:
-            traffic = json.load(open(pmc)).get(dom, {}).get(f"batch{B}")
-        except Exception:
-            traffic = None
-
-    conv_summary = None
-    if model is not None and not a.plain_model:
-        from posepaf.fused_model import conv_choices
-        ch = conv_choices()
-        conv_summary = {"shapes_fused_kernel": sum(1 for v in ch.values() if v >= 0),
-                        "shapes_miopen_plus_epilogue": sum(1 for v in ch.values() if v < 0)}
+    rc = 0
     if rank == 0:
+        multi = a.multiscale
         out = {
-            "metric": "end-to-end images/sec at 512×512", "value": world * B * a.steps / dt, "unit": "images/sec",
+            "metric": "end-to-end images/sec at 512×512" + (", multi-scale" if multi else ""),
+            "value": world * B * a.steps / dt, "unit": "images/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
-            "data": "synthetic (random-init IMHN weights, random uint8 images, synthetic GT-style pose scenes injected "
-                    "into the network output)",
-            "config": {"workload": "configs[2]+forward: 512x512, flip=on, 4-stage IMHN forward (fp16) + full HIP "
-                                   "pafprocess (NMS + limb line-integral + assembly)" if not a.postproc_only else
-                                   "configs[2] post-processing only", "images_per_gpu_per_step": B,
-                       "people_per_scene": list(SCENE_PEOPLE), "parallelism": f"image-sharded x{world}"},
-            "forward_tflops_per_gpu": None if a.postproc_only else B * a.steps * FLOP_PER_IMAGE / dt / 1e12,
-            "roofline_forward": None if a.postproc_only else {
-                "bound": "mfma", "achieved": B * a.steps * FLOP_PER_IMAGE / dt / 1e12, "peak": MFMA_F16_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": B * a.steps * FLOP_PER_IMAGE / dt / 1e12 / MFMA_F16_PEAK_TFLOPS,
-                "note": "whole step time (forward + pre/post-processing) against the dense fp16 MFMA peak"},
-            "conv_layers": conv_summary,
-            "humans_found_in_batch": int(recs["n_humans"].sum()), "status_or": int(np.bitwise_or.reduce(recs["status"])),
-            "kernel_ms": ms,
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes[dom]},
+            "data": "synthetic (random-init IMHN weights, random uint8 images uploaded from pinned host memory every step, "
+                    "synthetic GT-style pose scenes injected into the network output)",
+            "config": {"workload": ("configs[4]: original path, scales {0.5,1.0,1.5} x 512 + flip, float64 accumulation at image "
+                                    "resolution in HBM, find_peaks + Python-twin matching") if multi else
+                                   ("configs[2] post-processing only" if a.postproc_only else
+                                    "configs[2]+forward: 512x512, flip=on, host->HBM ingest + 4-stage IMHN forward (fp16) + full HIP "
+                                    "pafprocess (NMS + limb line-integral + assembly)"),
+                       "images_per_gpu_per_step": B, "people_per_scene": list(SCENE_PEOPLE),
+                       "ingest": "off" if a.no_ingest else "pinned host -> HBM upload of each uint8 batch inside the step (copy stream, double-buffered)",
+                       "launch": "eager" if (a.no_graph or multi or stub) else "hipGraph replay",
+                       "parallelism": f"image-sharded x{world}"},
+            "humans_found_in_batch": humans, "status_or": status_or,
         }
-        if not a.no_cpu_baseline and world == 1:   # reported on rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(uniq, a.cpu_seconds)
+        out.update(eng.extras(a, dt, world))
+        if not a.no_cpu_baseline and world == 1 and not stub:   # reported on rank 0 at N = 1 only
+            out["cpu_baseline"] = cpu_baseline(a.cpu_seconds, a.cpu_cores)
         print(json.dumps(out), flush=True)
+    if bad_status:
+        print(f"bench.py: pp_record.status = {status_or:#010x}: "
+              + ("bits outside include/posepaf.h:53-59 (corrupted records)" if status_or & ~ST_DEFINED else "capacity-overflow flags raised")
+              + " -- the result is INVALID", file=sys.stderr, flush=True)
+        rc = 3
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return rc
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -22,7 +22,7 @@ struct pp_ctx {
     int *d_counts = nullptr;      // [max_batch][18]
     float4 *d_conns = nullptr;    // [max_batch][30][maxp] (cid1 bits, cid2 bits, score, length)
     int *d_conn_counts = nullptr; // [max_batch][30]
-    unsigned *d_status = nullptr; // [max_batch]
+    unsigned *d_status = nullptr; // [max_batch][48] flag words, one per producing workgroup (posepaf_kernels.hip or_flags)
     void *d_conns_py = nullptr;   // [max_batch][30][maxp] double4 (src, dst, score, length): Python-twin path
     double *d_persons = nullptr;  // [128][40] raw person table of the Python-twin host form
     int *d_npersons = nullptr;
@@ -127,10 +127,11 @@ int pp_create(pp_ctx **out, int device, int max_batch, int max_h, int max_w, int
     if (e == hipSuccess) e = hipMalloc(&c->d_conns_py, B * PP_NUM_LIMB * c->maxp * 32);
     if (e == hipSuccess) e = hipMalloc(&c->d_persons, 128 * 40 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&c->d_npersons, sizeof(int));
-    if (e == hipSuccess) e = hipMalloc(&c->d_status, B * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc(&c->d_status, B * pp::kFlagWordsPerImage * sizeof(unsigned));
     if (e == hipSuccess) e = hipMalloc(&c->d_records, B * sizeof(pp_record));
     if (e == hipSuccess) e = hipMemset(c->d_counts, 0, B * PP_NUM_PART * sizeof(int));
     if (e == hipSuccess) e = hipMemset(c->d_conn_counts, 0, B * PP_NUM_LIMB * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(c->d_status, 0, B * pp::kFlagWordsPerImage * sizeof(unsigned));
     if (e != hipSuccess) {
         free_ctx(c);
         return PP_ERR_HIP;
@@ -166,7 +167,6 @@ int pp_nms_batch_ex(pp_ctx *ctx, int batch, const void *net_out_dev, int dtype, 
     hipStream_t st = static_cast<hipStream_t>(stream);
     float4 *pk = peaks_dev ? reinterpret_cast<float4 *>(peaks_dev) : ctx->d_peaks;
     int *cn = counts_dev ? counts_dev : ctx->d_counts;
-    PP_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(unsigned) * (size_t)batch, st));
     PP_HIP(ctx, pp::launch_heat_peaks(net_out_dev, dtype, batch, flip ? 2 : 1, h, w, flip, refine, nms_mode, threshold,
                                       ctx->maxp, pk, cn, ctx->d_status, st));
     ctx->last_stream = st;
@@ -184,14 +184,13 @@ int pp_process_batch(pp_ctx *ctx, int batch, const void *net_out_dev, int dtype,
     hipStream_t st = static_cast<hipStream_t>(stream);
     pp_record *rec = records_dev ? records_dev : ctx->d_records;
     const int ns = flip ? 2 : 1;
-    PP_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(unsigned) * (size_t)batch, st));
     PP_HIP(ctx, pp::launch_heat_peaks(net_out_dev, dtype, batch, ns, h, w, flip, 1, 0, 0.1f, ctx->maxp, ctx->d_peaks,
                                       ctx->d_counts, ctx->d_status, st));
     PP_HIP(ctx, pp::launch_limb_connect(net_out_dev, dtype, batch, ns, h, w, flip, ctx->maxp, ctx->cap, min_img_size,
                                         min_img_size_dev, ctx->d_peaks, ctx->d_counts, ctx->d_conns, ctx->d_conn_counts,
                                         ctx->d_status, st));
     PP_HIP(ctx, pp::launch_assemble(batch, ctx->maxp, 0, ctx->d_peaks, ctx->d_counts, ctx->d_conns, ctx->d_conn_counts,
-                                    ctx->d_status, rec, st));
+                                    ctx->d_status, 0, rec, st));
     ctx->last_stream = st;
     ctx->last_batch = batch;
     ctx->last_peaks = ctx->d_peaks;
@@ -211,14 +210,13 @@ int pp_process_batch_py(pp_ctx *ctx, int batch, const void *net_out_dev, int dty
     hipStream_t st = static_cast<hipStream_t>(stream);
     pp_record *rec = records_dev ? records_dev : ctx->d_records;
     const int ns = flip ? 2 : 1;
-    PP_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(unsigned) * (size_t)batch, st));
     PP_HIP(ctx, pp::launch_heat_peaks(net_out_dev, dtype, batch, ns, h, w, flip, 1, 0, 0.1f, ctx->maxp, ctx->d_peaks,
                                       ctx->d_counts, ctx->d_status, st));
     PP_HIP(ctx, pp::launch_limb_connect_py(net_out_dev, dtype, batch, ns, h, w, flip, ctx->maxp, ctx->cap, img_height,
                                            img_height_dev, ctx->d_peaks, ctx->d_counts, ctx->d_conns_py, ctx->d_conn_counts,
                                            ctx->d_status, st));
     PP_HIP(ctx, pp::launch_assemble_py(batch, ctx->maxp, 0, ctx->d_peaks, ctx->d_counts, ctx->d_conns_py, ctx->d_conn_counts,
-                                       ctx->d_status, rec, nullptr, nullptr, st));
+                                       ctx->d_status, 0, rec, nullptr, nullptr, st));
     ctx->last_stream = st;
     ctx->last_batch = batch;
     ctx->last_peaks = ctx->d_peaks;
@@ -239,10 +237,13 @@ int pp_time_kernels(pp_ctx *ctx, int batch, const void *net_out_dev, int dtype, 
     // one untimed pass so that every kernel's inputs exist
     rc = pp_process_batch(ctx, batch, net_out_dev, dtype, h, w, flip, min_img_size, nullptr, nullptr, st);
     if (rc != PP_OK) return rc;
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < 4; k++) {
         PP_HIP(ctx, hipEventRecord(e0, st));
         for (int i = 0; i < iters; i++) {
-            if (k == 0)
+            if (k == 3) {  // the whole chain, back to back, as pp_process_batch enqueues it
+                rc = pp_process_batch(ctx, batch, net_out_dev, dtype, h, w, flip, min_img_size, nullptr, nullptr, st);
+                if (rc != PP_OK) return rc;
+            } else if (k == 0)
                 PP_HIP(ctx, pp::launch_heat_peaks(net_out_dev, dtype, batch, ns, h, w, flip, 1, 0, 0.1f, ctx->maxp,
                                                   ctx->d_peaks, ctx->d_counts, ctx->d_status, st));
             else if (k == 1)
@@ -251,7 +252,7 @@ int pp_time_kernels(pp_ctx *ctx, int batch, const void *net_out_dev, int dtype, 
                                                     ctx->d_conn_counts, ctx->d_status, st));
             else
                 PP_HIP(ctx, pp::launch_assemble(batch, ctx->maxp, 0, ctx->d_peaks, ctx->d_counts, ctx->d_conns,
-                                                ctx->d_conn_counts, ctx->d_status, ctx->d_records, st));
+                                                ctx->d_conn_counts, ctx->d_status, 0, ctx->d_records, st));
         }
         PP_HIP(ctx, hipEventRecord(e1, st));
         PP_HIP(ctx, hipEventSynchronize(e1));
@@ -314,6 +315,30 @@ int pp_read_connections(pp_ctx *ctx, int image, int limb, float *rows_host, int 
     return PP_OK;
 }
 
+int pp_read_part_counts(pp_ctx *ctx, int image, int *counts_host) {
+    if (!ctx || !counts_host || image < 0 || image >= ctx->last_batch) return PP_ERR_BAD_ARG;
+    PP_HIP(ctx, hipStreamSynchronize(ctx->last_stream));
+    PP_HIP(ctx, hipMemcpy(counts_host, ctx->d_counts + (size_t)image * PP_NUM_PART, sizeof(int) * PP_NUM_PART,
+                          hipMemcpyDeviceToHost));
+    return PP_OK;
+}
+
+int pp_read_connection_counts(pp_ctx *ctx, int image, int *counts_host) {
+    if (!ctx || !counts_host || image < 0 || image >= ctx->last_batch) return PP_ERR_BAD_ARG;
+    PP_HIP(ctx, hipStreamSynchronize(ctx->last_stream));
+    PP_HIP(ctx, hipMemcpy(counts_host, ctx->d_conn_counts + (size_t)image * PP_NUM_LIMB, sizeof(int) * PP_NUM_LIMB,
+                          hipMemcpyDeviceToHost));
+    return PP_OK;
+}
+
+int pp_debug_read_flags(pp_ctx *ctx, int image, uint32_t *flags_host) {
+    if (!ctx || !flags_host || image < 0 || image >= ctx->max_batch) return PP_ERR_BAD_ARG;
+    PP_HIP(ctx, hipStreamSynchronize(ctx->last_stream));
+    PP_HIP(ctx, hipMemcpy(flags_host, ctx->d_status + (size_t)image * pp::kFlagWordsPerImage,
+                          sizeof(uint32_t) * pp::kFlagWordsPerImage, hipMemcpyDeviceToHost));
+    return PP_OK;
+}
+
 int pp_read_records(pp_ctx *ctx, const pp_record *records_dev, pp_record *records_host, int batch, void *stream) {
     if (!ctx || !records_host || batch <= 0 || batch > ctx->max_batch) return PP_ERR_BAD_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -372,11 +397,10 @@ int pp_process_paf_host(pp_ctx *ctx, int p1, int p2, int p3, const float *peaks,
     PP_HIP(ctx, hipMemcpyAsync(ctx->d_paf, pafmap, paf_bytes, hipMemcpyHostToDevice, st));
     PP_HIP(ctx, hipMemcpyAsync(ctx->d_peaks, pk.data(), pk.size() * sizeof(float4), hipMemcpyHostToDevice, st));
     PP_HIP(ctx, hipMemcpyAsync(ctx->d_counts, counts, sizeof(counts), hipMemcpyHostToDevice, st));
-    PP_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(unsigned), st));
     PP_HIP(ctx, pp::launch_limb_connect_hwc(ctx->d_paf, f1, f2, f3, maxp, ctx->cap, min_img_size, ctx->d_peaks,
                                             ctx->d_counts, ctx->d_conns, ctx->d_conn_counts, ctx->d_status, st));
     PP_HIP(ctx, pp::launch_assemble(1, maxp, 1, ctx->d_peaks, ctx->d_counts, ctx->d_conns, ctx->d_conn_counts,
-                                    ctx->d_status, ctx->d_records, st));
+                                    ctx->d_status, PP_NUM_PART, ctx->d_records, st));  // no peak kernel ran: limb words only
     PP_HIP(ctx, hipMemcpyAsync(&ctx->h_record, ctx->d_records, sizeof(pp_record), hipMemcpyDeviceToHost, st));
     PP_HIP(ctx, hipStreamSynchronize(st));
     ctx->last_stream = st;
@@ -445,7 +469,6 @@ int pp_original_finish(pp_ctx *ctx, int batch, int img_h, int img_w, float thre1
     if (pp::lds_bytes_assemble_py(ctx->maxp) > pp::kMaxDynLds) return PP_ERR_TOO_LARGE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     pp_record *rec = records_dev ? records_dev : ctx->d_records;
-    PP_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(unsigned) * (size_t)batch, st));
     PP_HIP(ctx, pp::launch_fullres(batch, img_h, img_w, thre1, ctx->maxp, ctx->cap, img_h, heat_acc, paf_acc, mask_scratch,
                                    peaks64_scratch, ctx->d_counts, ctx->d_conns_py, ctx->d_conn_counts, ctx->d_status, rec, st));
     ctx->last_stream = st;
@@ -498,15 +521,16 @@ int pp_py_find_connections_host(pp_ctx *ctx, const float *peaks, int n, const fl
     PP_HIP(ctx, hipMemcpyAsync(ctx->d_paf, paf, paf_bytes, hipMemcpyHostToDevice, st));
     PP_HIP(ctx, hipMemcpyAsync(ctx->d_peaks, pk.data(), pk.size() * sizeof(float4), hipMemcpyHostToDevice, st));
     PP_HIP(ctx, hipMemcpyAsync(ctx->d_counts, counts, sizeof(counts), hipMemcpyHostToDevice, st));
-    PP_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(unsigned), st));
     PP_HIP(ctx, pp::launch_limb_connect_py_hwc(ctx->d_paf, H, W, C, maxp, ctx->cap, img_height, ctx->d_peaks, ctx->d_counts,
                                                ctx->d_conns_py, ctx->d_conn_counts, ctx->d_status, st));
     std::vector<double> raw((size_t)PP_NUM_LIMB * maxp * 4);
     PP_HIP(ctx, hipMemcpyAsync(raw.data(), ctx->d_conns_py, raw.size() * sizeof(double), hipMemcpyDeviceToHost, st));
     PP_HIP(ctx, hipMemcpyAsync(counts_out, ctx->d_conn_counts, sizeof(int) * PP_NUM_LIMB, hipMemcpyDeviceToHost, st));
-    unsigned status = 0;
-    PP_HIP(ctx, hipMemcpyAsync(&status, ctx->d_status, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    unsigned limb_flags[PP_NUM_LIMB];
+    PP_HIP(ctx, hipMemcpyAsync(limb_flags, ctx->d_status + PP_NUM_PART, sizeof(limb_flags), hipMemcpyDeviceToHost, st));
     PP_HIP(ctx, hipStreamSynchronize(st));
+    unsigned status = 0;
+    for (unsigned f : limb_flags) status |= f;
     if (status & PP_ST_CAND_OVERFLOW) return PP_ERR_OVERFLOW;
     static const int LP[PP_NUM_LIMB][2] = {{1, 0},   {1, 14},  {1, 15},  {1, 16},  {1, 17},  {0, 14},  {0, 15},  {14, 16},
                                            {15, 17}, {1, 2},   {2, 3},   {3, 4},   {1, 5},   {5, 6},   {6, 7},   {1, 8},
@@ -559,9 +583,9 @@ int pp_py_find_humans_host(pp_ctx *ctx, const double *conns, const int *counts_l
     PP_HIP(ctx, hipMemcpyAsync(ctx->d_counts, counts, sizeof(counts), hipMemcpyHostToDevice, st));
     PP_HIP(ctx, hipMemcpyAsync(ctx->d_conns_py, raw.data(), raw.size() * sizeof(double), hipMemcpyHostToDevice, st));
     PP_HIP(ctx, hipMemcpyAsync(ctx->d_conn_counts, cl, sizeof(cl), hipMemcpyHostToDevice, st));
-    PP_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(unsigned), st));
     PP_HIP(ctx, pp::launch_assemble_py(1, maxp, 1, ctx->d_peaks, ctx->d_counts, ctx->d_conns_py, ctx->d_conn_counts,
-                                       ctx->d_status, ctx->d_records, ctx->d_persons, ctx->d_npersons, st));
+                                       ctx->d_status, pp::kFlagWordsPerImage, ctx->d_records, ctx->d_persons, ctx->d_npersons,
+                                       st));  // connections come from the caller: no kernel wrote a flag word
     int np = 0;
     PP_HIP(ctx, hipMemcpyAsync(&np, ctx->d_npersons, sizeof(int), hipMemcpyDeviceToHost, st));
     PP_HIP(ctx, hipStreamSynchronize(st));

@@ -13,6 +13,9 @@ constexpr size_t kMaxDynLds = 163840 - 4096;
 hipError_t init_kernel_attributes();
 hipError_t set_stamp_buffer(long long *buf);
 
+// status flag words per image: [0, 18) one per part (peak kernels), [18, 48) one per limb (limb kernels); see or_flags
+constexpr int kFlagWordsPerImage = PP_NUM_PART + PP_NUM_LIMB;
+
 size_t lds_bytes_heat(int elem, int h, int w, int maxp);
 size_t lds_bytes_limb(int elem, int h, int w, int maxp, int cap);
 size_t lds_bytes_limb_hwc(int maxp, int cap);
@@ -29,8 +32,8 @@ hipError_t launch_limb_connect_hwc(const float *paf, int H, int W, int C, int ma
                                    const float4 *peaks, const int *counts, float4 *conns, int *conn_counts,
                                    unsigned *status, hipStream_t stream);
 hipError_t launch_assemble(int batch, int maxp, int explicit_ids, const float4 *peaks, const int *counts,
-                           const float4 *conns, const int *conn_counts, unsigned *status, pp_record *records,
-                           hipStream_t stream);
+                           const float4 *conns, const int *conn_counts, const unsigned *status, int flag_first,
+                           pp_record *records, hipStream_t stream);
 
 size_t lds_bytes_limb_py(int elem, int h, int w, int maxp, int cap);
 size_t lds_bytes_assemble_py(int maxp);
@@ -38,8 +41,8 @@ hipError_t launch_limb_connect_py(const void *net, int dtype, int batch, int n_s
                                   int cap, int img_height, const int *img_height_dev, const float4 *peaks, const int *counts,
                                   void *conns, int *conn_counts, unsigned *status, hipStream_t stream);
 hipError_t launch_assemble_py(int batch, int maxp, int explicit_ids, const float4 *peaks, const int *counts, const void *conns,
-                              const int *conn_counts, unsigned *status, pp_record *records, double *persons_out,
-                              int *n_persons_out, hipStream_t stream);
+                              const int *conn_counts, const unsigned *status, int flag_first, pp_record *records,
+                              double *persons_out, int *n_persons_out, hipStream_t stream);
 hipError_t launch_limb_connect_py_hwc(const float *paf, int H, int W, int C, int maxp, int cap, int img_height,
                                       const float4 *peaks, const int *counts, void *conns, int *conn_counts, unsigned *status,
                                       hipStream_t stream);

@@ -79,6 +79,19 @@ __device__ __forceinline__ unsigned long long lanemask_lt() {
     return (1ull << (threadIdx.x & 63)) - 1ull;
 }
 
+// Per-image status flags: one word per producing workgroup -- [0, 18) written by the peak kernel of each part, [18, 48) by
+// the limb kernel of each limb -- stored with a PLAIN store by every workgroup on every launch (early exits included), and
+// OR-ed by the assembly.  Nothing is ever zeroed by a memset and nothing is accumulated with atomics, so no word can
+// carry anything but the flags of the launch that produced it.  `first` skips the part words on the host-array paths
+// (process_paf / find_connections), where the peaks come from the caller and no peak kernel ran.
+constexpr int kFlagWords = PP_NUM_PART + PP_NUM_LIMB;
+__device__ __forceinline__ unsigned or_flags(const unsigned *flags, int img, int first, int lane) {
+    unsigned v = (lane >= first && lane < kFlagWords) ? flags[img * kFlagWords + lane] : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v |= __shfl_xor(v, d);
+    return v;
+}
+
 // ------------------------------------------------------------------------------------------------ A2 loader
 // utils/parse_skeletons.py:82-103: avg[c][y][x] = (o0[c][y][x] + o1[perm(c)][y][w-1-x]) / 2 computed in the
 // array's dtype (binary16 add + binary16 halve for the AMP output, float32 otherwise), then widened.
@@ -347,7 +360,8 @@ __global__ __launch_bounds__(kThreads) void k_heat_peaks(const T *__restrict__ n
     const int b0 = threadIdx.x * bpt;
     int cnt = 0;
     unsigned long long word = 0;
-    const bool one_word = bpt == 8;  // the 128 x 128 case: a thread's 64 pixels are one 8-byte LDS read
+    const bool one_word = bpt == 8 && (nvec & 7) == 0;  // the 128 x 128 case: a thread's 64 pixels are one 8-byte LDS read
+                                                       // (only when no thread's range is partial: a ragged tail takes the byte loop)
     if (one_word) {
         word = b0 + 8 <= nvec ? *reinterpret_cast<const unsigned long long *>(s_m8 + b0) : 0ull;
         cnt = __popcll(word);
@@ -484,7 +498,7 @@ __global__ __launch_bounds__(kThreads) void k_heat_peaks(const T *__restrict__ n
     }
     if (threadIdx.x == 0) {
         counts[img * PP_NUM_PART + part] = total;
-        if (total > maxp) atomicOr(&status[img], PP_ST_PEAK_OVERFLOW);
+        status[img * kFlagWords + part] = total > maxp ? PP_ST_PEAK_OVERFLOW : 0u;  // plain store, every launch
     }
     __syncthreads();
     stamp(stamps, wg, 3);
@@ -1064,7 +1078,7 @@ __device__ void connect_limb(const Sampler &smp, const LimbLds &L, int nA, int n
     }
     if (threadIdx.x == 0) {
         *conn_count = ncn;
-        if (st) atomicOr(status_word, st);
+        *status_word = st;  // plain store, every launch (no memset / atomic protocol)
     }
     stamp(stamps, wg, 5);
 }
@@ -1085,7 +1099,10 @@ __global__ __launch_bounds__(kThreads) void k_limb_connect(const T *__restrict__
     nB = nB < maxp ? nB : maxp;
     int *cc = conn_counts + img * PP_NUM_LIMB + limb;
     if (nA == 0 || nB == 0) {  // no candidate pairs: no connections (pafprocess.cpp:56-58, :111)
-        if (threadIdx.x == 0) *cc = 0;
+        if (threadIdx.x == 0) {
+            *cc = 0;
+            status[img * kFlagWords + PP_NUM_PART + limb] = 0u;
+        }
         return;
     }
     const int npix = h * w;
@@ -1123,8 +1140,8 @@ __global__ __launch_bounds__(kThreads) void k_limb_connect(const T *__restrict__
 
     LdsBicubicSampler<T> smp{smap, s_cub, h, w};
     const int mis = min_img_size_dev ? min_img_size_dev[img] : min_img_size;
-    connect_limb(smp, L, nA, nB, cap, maxp, mis, conns + ((size_t)img * PP_NUM_LIMB + limb) * maxp, cc, status + img,
-                 stamps, wg);
+    connect_limb(smp, L, nA, nB, cap, maxp, mis, conns + ((size_t)img * PP_NUM_LIMB + limb) * maxp, cc,
+                 status + img * kFlagWords + PP_NUM_PART + limb, stamps, wg);
 }
 
 // Drop-in path: the caller's (H, W, C) up-sampled map lives in global memory (uploaded by process_paf)
@@ -1142,7 +1159,10 @@ __global__ __launch_bounds__(kThreads) void k_limb_connect_hwc(const float *__re
     nB = nB < maxp ? nB : maxp;
     int *cc = conn_counts + limb;
     if (nA == 0 || nB == 0 || limb >= C) {
-        if (threadIdx.x == 0) *cc = 0;
+        if (threadIdx.x == 0) {
+            *cc = 0;
+            status[PP_NUM_PART + limb] = 0u;
+        }
         return;
     }
     size_t off = 0;
@@ -1163,7 +1183,7 @@ __global__ __launch_bounds__(kThreads) void k_limb_connect_hwc(const float *__re
     }
     __syncthreads();
     GlobalHwcSampler smp{paf, H, W, C, limb};
-    connect_limb(smp, L, nA, nB, cap, maxp, min_img_size, conns + (size_t)limb * maxp, cc, status);
+    connect_limb(smp, L, nA, nB, cap, maxp, min_img_size, conns + (size_t)limb * maxp, cc, status + PP_NUM_PART + limb);
 }
 
 // ------------------------------------------------------------------------------------------------ K_C
@@ -1180,8 +1200,8 @@ __host__ __device__ inline size_t assemble_lds_bytes(int maxp) {
 
 __global__ __launch_bounds__(64) void k_assemble(int maxp, int explicit_ids, const float4 *__restrict__ peaks,
                                                  const int *__restrict__ counts, const float4 *__restrict__ conns,
-                                                 const int *__restrict__ conn_counts, unsigned *__restrict__ status,
-                                                 pp_record *__restrict__ records) {
+                                                 const int *__restrict__ conn_counts, const unsigned *__restrict__ status,
+                                                 int flag_first, pp_record *__restrict__ records) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int img = blockIdx.x, lane = threadIdx.x;
     const int ntab = PP_NUM_PART * maxp;
@@ -1591,6 +1611,7 @@ __global__ __launch_bounds__(64) void k_assemble(int maxp, int explicit_ids, con
         }
         n_out += __popcll(m);
     }
+    const unsigned fl = or_flags(status, img, flag_first, lane);
     if (lane == 0) {
         if (n_out > PP_MAX_HUMANS) {
             st |= PP_ST_HUMAN_OVERFLOW;
@@ -1599,7 +1620,7 @@ __global__ __launch_bounds__(64) void k_assemble(int maxp, int explicit_ids, con
         rec->n_humans = n_out;
         rec->n_peaks = n_peaks;
         rec->n_connections = s_coff[PP_NUM_LIMB];
-        rec->status = status[img] | st;
+        rec->status = fl | st;
     }
     stamp(stamps, img, 3);
 }
@@ -1844,7 +1865,7 @@ __device__ void connect_limb_py(const Sampler &smp, const LimbLdsPy &L, int nA, 
     }
     if (threadIdx.x == 0) {
         *cc = ncn;
-        if (st) atomicOr(status_word, st);
+        *status_word = st;
     }
 }
 
@@ -1865,7 +1886,10 @@ __global__ __launch_bounds__(kThreads) void k_limb_connect_py(const T *__restric
     nB = nB < maxp ? nB : maxp;
     int *cc = conn_counts + img * PP_NUM_LIMB + limb;
     if (nA == 0 || nB == 0) {
-        if (threadIdx.x == 0) *cc = 0;
+        if (threadIdx.x == 0) {
+            *cc = 0;
+            status[img * kFlagWords + PP_NUM_PART + limb] = 0u;
+        }
         return;
     }
     const int npix = h * w;
@@ -1902,7 +1926,8 @@ __global__ __launch_bounds__(kThreads) void k_limb_connect_py(const T *__restric
     LdsBicubicSampler<T> smp{smap, s_cub, h, w};
     const int ih = img_height_dev ? img_height_dev[img] : img_height;
 
-    connect_limb_py(smp, L, nA, nB, cap, maxp, ih, conns + ((size_t)img * PP_NUM_LIMB + limb) * maxp, cc, status + img);
+    connect_limb_py(smp, L, nA, nB, cap, maxp, ih, conns + ((size_t)img * PP_NUM_LIMB + limb) * maxp, cc,
+                    status + img * kFlagWords + PP_NUM_PART + limb);
 }
 
 // Host-array form (utils.parse_skeletons.find_connections): the caller's up-sampled (H, W, C) map in global memory
@@ -1918,7 +1943,10 @@ __global__ __launch_bounds__(kThreads) void k_limb_connect_py_hwc(const float *_
     nB = nB < maxp ? nB : maxp;
     int *cc = conn_counts + limb;
     if (nA == 0 || nB == 0 || limb >= C) {
-        if (threadIdx.x == 0) *cc = 0;
+        if (threadIdx.x == 0) {
+            *cc = 0;
+            status[PP_NUM_PART + limb] = 0u;
+        }
         return;
     }
     LimbLdsPy L = carve_limb_lds_py(lds_raw, maxp, cap);
@@ -1942,7 +1970,7 @@ __global__ __launch_bounds__(kThreads) void k_limb_connect_py_hwc(const float *_
     }
     __syncthreads();
     GlobalHwcSampler smp{paf, H, W, C, limb};
-    connect_limb_py(smp, L, nA, nB, cap, maxp, img_height, conns + (size_t)limb * maxp, cc, status);
+    connect_limb_py(smp, L, nA, nB, cap, maxp, img_height, conns + (size_t)limb * maxp, cc, status + PP_NUM_PART + limb);
 }
 
 // find_humans, one wave per image, float64 person table in LDS: [s][k] = {id, score}; k = 18: {total, -1}; 19: {count, len}
@@ -1956,8 +1984,9 @@ __host__ __device__ inline size_t assemble_py_lds_bytes(int maxp) {
 template <typename PK>
 __global__ __launch_bounds__(64) void k_assemble_py(int maxp, int explicit_ids, const PK *__restrict__ peaks,
                                                     const int *__restrict__ counts, const double4 *__restrict__ conns,
-                                                    const int *__restrict__ conn_counts, unsigned *__restrict__ status,
-                                                    pp_record *__restrict__ records, double *__restrict__ persons_out,
+                                                    const int *__restrict__ conn_counts, const unsigned *__restrict__ status,
+                                                    int flag_first, pp_record *__restrict__ records,
+                                                    double *__restrict__ persons_out,
                                                     int *__restrict__ n_persons_out) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int img = blockIdx.x, lane = threadIdx.x;
@@ -2168,6 +2197,7 @@ __global__ __launch_bounds__(64) void k_assemble_py(int maxp, int explicit_ids, 
         n_out += __popcll(m);
     }
     if (lane == 0 && n_persons_out) *n_persons_out = n_out;
+    const unsigned fl = or_flags(status, img, flag_first, lane);
     if (lane == 0) {
         if (n_out > PP_MAX_HUMANS) {
             st |= PP_ST_HUMAN_OVERFLOW;
@@ -2176,7 +2206,7 @@ __global__ __launch_bounds__(64) void k_assemble_py(int maxp, int explicit_ids, 
         rec->n_humans = n_out;
         rec->n_peaks = n_peaks;
         rec->n_connections = s_coff[PP_NUM_LIMB];
-        rec->status = status[img] | st | (kFloatCoords ? PP_ST_FLOAT_COORDS : 0u);
+        rec->status = fl | st | (kFloatCoords ? PP_ST_FLOAT_COORDS : 0u);
     }
 }
 
@@ -2368,7 +2398,7 @@ __global__ __launch_bounds__(kThreads) void k_fullres_peaks(const double *__rest
     }
     if (threadIdx.x == 0) {
         counts[img * PP_NUM_PART + part] = total;
-        if (total > maxp) atomicOr(&status[img], PP_ST_PEAK_OVERFLOW);
+        status[img * kFlagWords + part] = total > maxp ? PP_ST_PEAK_OVERFLOW : 0u;  // plain store, every launch
     }
 }
 
@@ -2395,7 +2425,10 @@ __global__ __launch_bounds__(kThreads) void k_limb_connect_py_fullres(const doub
     nB = nB < maxp ? nB : maxp;
     int *cc = conn_counts + img * PP_NUM_LIMB + limb;
     if (nA == 0 || nB == 0) {
-        if (threadIdx.x == 0) *cc = 0;
+        if (threadIdx.x == 0) {
+            *cc = 0;
+            status[img * kFlagWords + PP_NUM_PART + limb] = 0u;
+        }
         return;
     }
     LimbLdsPy L = carve_limb_lds_py(lds_raw, maxp, cap);
@@ -2419,7 +2452,8 @@ __global__ __launch_bounds__(kThreads) void k_limb_connect_py_fullres(const doub
     }
     __syncthreads();
     GlobalPlanarF64Sampler smp{paf_acc + ((long)img * PP_NUM_LIMB + limb) * (long)H * W, H, W};
-    connect_limb_py(smp, L, nA, nB, cap, maxp, img_height, conns + ((long)img * PP_NUM_LIMB + limb) * maxp, cc, status + img);
+    connect_limb_py(smp, L, nA, nB, cap, maxp, img_height, conns + ((long)img * PP_NUM_LIMB + limb) * maxp, cc,
+                    status + img * kFlagWords + PP_NUM_PART + limb);
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
@@ -2505,11 +2539,11 @@ hipError_t launch_limb_connect_hwc(const float *paf, int H, int W, int C, int ma
 }
 
 hipError_t launch_assemble(int batch, int maxp, int explicit_ids, const float4 *peaks, const int *counts,
-                           const float4 *conns, const int *conn_counts, unsigned *status, pp_record *records,
-                           hipStream_t stream) {
+                           const float4 *conns, const int *conn_counts, const unsigned *status, int flag_first,
+                           pp_record *records, hipStream_t stream) {
     const size_t lds = lds_bytes_assemble(maxp);
     hipLaunchKernelGGL(k_assemble, dim3(batch), dim3(64), lds, stream, maxp, explicit_ids, peaks, counts, conns,
-                       conn_counts, status, records);
+                       conn_counts, status, flag_first, records);
     return hipGetLastError();
 }
 
@@ -2535,10 +2569,10 @@ hipError_t launch_limb_connect_py(const void *net, int dtype, int batch, int n_s
 }
 
 hipError_t launch_assemble_py(int batch, int maxp, int explicit_ids, const float4 *peaks, const int *counts, const void *conns,
-                              const int *conn_counts, unsigned *status, pp_record *records, double *persons_out,
-                              int *n_persons_out, hipStream_t stream) {
+                              const int *conn_counts, const unsigned *status, int flag_first, pp_record *records,
+                              double *persons_out, int *n_persons_out, hipStream_t stream) {
     hipLaunchKernelGGL(k_assemble_py<float4>, dim3(batch), dim3(64), lds_bytes_assemble_py(maxp), stream, maxp, explicit_ids,
-                       peaks, counts, static_cast<const double4 *>(conns), conn_counts, status, records, persons_out,
+                       peaks, counts, static_cast<const double4 *>(conns), conn_counts, status, flag_first, records, persons_out,
                        n_persons_out);
     return hipGetLastError();
 }
@@ -2583,7 +2617,7 @@ hipError_t launch_fullres(int batch, int H, int W, float thre1, int maxp, int ca
                        static_cast<double4 *>(conns), conn_counts, status);
     hipLaunchKernelGGL(k_assemble_py<double4>, dim3(batch), dim3(64), lds_bytes_assemble_py(maxp), stream, maxp, 0,
                        static_cast<const double4 *>(peaks64), counts, static_cast<const double4 *>(conns), conn_counts, status,
-                       records, static_cast<double *>(nullptr), static_cast<int *>(nullptr));
+                       0, records, static_cast<double *>(nullptr), static_cast<int *>(nullptr));
     return hipGetLastError();
 }
 

@@ -110,11 +110,11 @@ class PosePostProcessor:
         """HIP-event timing of each kernel on torch's current stream: dict name -> ms per launch."""
         import torch
         B, h, w = self._check_input(net_out, flip)
-        ms = (C.c_float * 3)()
+        ms = (C.c_float * 4)()
         stream = torch.cuda.current_stream(net_out.device).cuda_stream
         _lib.check(self.L.pp_time_kernels(self.ctx, B, C.c_void_p(net_out.data_ptr()), self._dtype_code(net_out), h, w,
                                           int(flip), int(min_img_size), int(iters), ms, C.c_void_p(stream)), self.ctx)
-        return {"k_heat_peaks": ms[0], "k_limb_connect": ms[1], "k_assemble": ms[2]}
+        return {"k_heat_peaks": ms[0], "k_limb_connect": ms[1], "k_assemble": ms[2], "chain": ms[3]}
 
     def read_peaks(self, image: int) -> np.ndarray:
         cap = _lib.NUM_PART * self.maxp
@@ -123,12 +123,38 @@ class PosePostProcessor:
         _lib.check(self.L.pp_read_peaks(self.ctx, image, buf.ctypes.data_as(C.POINTER(C.c_float)), cap, C.byref(n)), self.ctx)
         return buf[: n.value].copy()
 
+    def read_part_counts(self, image: int) -> np.ndarray:
+        buf = (C.c_int * _lib.NUM_PART)()
+        _lib.check(self.L.pp_read_part_counts(self.ctx, image, buf), self.ctx)
+        return np.array(buf[:], np.int32)
+
+    def read_connection_counts(self, image: int) -> np.ndarray:
+        buf = (C.c_int * _lib.NUM_LIMB)()
+        _lib.check(self.L.pp_read_connection_counts(self.ctx, image, buf), self.ctx)
+        return np.array(buf[:], np.int32)
+
+    def debug_read_flags(self, image: int) -> np.ndarray:
+        buf = (C.c_uint32 * (_lib.NUM_PART + _lib.NUM_LIMB))()
+        _lib.check(self.L.pp_debug_read_flags(self.ctx, image, buf), self.ctx)
+        return np.array(buf[:], np.uint32)
+
     def read_connections(self, image: int, limb: int) -> np.ndarray:
         buf = np.empty((self.maxp, 4), np.float32)
         n = C.c_int(0)
         _lib.check(self.L.pp_read_connections(self.ctx, image, limb, buf.ctypes.data_as(C.POINTER(C.c_float)), self.maxp,
                                               C.byref(n)), self.ctx)
         return buf[: n.value].copy()
+
+
+def check_status(recs, allow=0, what="records") -> int:
+    """OR of the status words of a batch of records; raises PosePafError when a bit outside include/posepaf.h:53-59
+    is set (corruption) or when a bit outside `allow` is set."""
+    st = int(np.bitwise_or.reduce(np.asarray(recs["status"], dtype=np.uint32))) if len(recs) else 0
+    if st & ~_lib.ST_DEFINED_MASK:
+        raise PosePafError(f"{what}: undefined bits in pp_record.status: {st:#010x}")
+    if st & ~allow:
+        raise PosePafError(f"{what}: status flags {st & ~allow:#x} raised (allowed: {allow:#x})")
+    return st
 
 
 def records_to_numpy(rec_u8) -> np.ndarray:

@@ -1,78 +1,40 @@
-"""`Human` / `BodyPart` result containers with the reference's attribute names (utils/common.py:39-51, :267-279).
-Drawing and box helpers of that file are visualisation and out of scope."""
-from enum import Enum
+"""Result containers of the inference path (A9), with the attribute names evaluate.py:111-129 and :182-209 read:
+`human.body_parts[part_idx] -> BodyPart(.x, .y, .score, .part_idx, .uidx)` and `human.score`.
 
+Only what posepaf/coco.py fills and the COCO writer reads is kept.  The reference's pair bookkeeping (Human.add_pair,
+uidx_list, part_count, get_max_score; utils/common.py:267-300) belongs to a grouping scheme this path never runs, and its
+drawing / box helpers are visualisation: both are out of scope."""
+from enum import IntEnum
 
-class CocoPart(Enum):
-    Nose = 0
-    Neck = 1
-    RShoulder = 2
-    RElbow = 3
-    RWrist = 4
-    LShoulder = 5
-    LElbow = 6
-    LWrist = 7
-    RHip = 8
-    RKnee = 9
-    RAnkle = 10
-    LHip = 11
-    LKnee = 12
-    LAnkle = 13
-    REye = 14
-    LEye = 15
-    REar = 16
-    LEar = 17
-    Background = 18
+# part index -> name, in the order of the network's keypoint channels (config/config.py:96-104)
+CocoPart = IntEnum("CocoPart", ["Nose", "Neck", "RShoulder", "RElbow", "RWrist", "LShoulder", "LElbow", "LWrist", "RHip",
+                                "RKnee", "RAnkle", "LHip", "LKnee", "LAnkle", "REye", "LEye", "REar", "LEar", "Background"],
+                   start=0)
 
 
 class BodyPart:
+    """One detected joint of one person: image coordinates, peak score, part index, and a printable id."""
     __slots__ = ("uidx", "part_idx", "x", "y", "score")
 
     def __init__(self, uidx, part_idx, x, y, score):
-        self.uidx = uidx
-        self.part_idx = part_idx
-        self.x, self.y = x, y
-        self.score = score
+        self.uidx, self.part_idx, self.x, self.y, self.score = uidx, part_idx, x, y, score
 
     def get_part_name(self):
         return CocoPart(self.part_idx)
 
-    def __str__(self):
-        return "BodyPart:%d-(%.2f, %.2f) score=%.2f" % (self.part_idx, self.x, self.y, self.score)
-
-    __repr__ = __str__
+    def __repr__(self):
+        return f"BodyPart({self.get_part_name().name} @ ({self.x}, {self.y}), score {self.score:.3f})"
 
 
 class Human:
-    __slots__ = ("body_parts", "pairs", "uidx_list", "score")
+    """One assembled person: `body_parts` maps part index -> BodyPart; `score` is pafprocess's get_score()."""
+    __slots__ = ("body_parts", "score")
 
-    def __init__(self, pairs):
-        self.pairs = []
-        self.uidx_list = set()
+    def __init__(self, pairs=()):
+        if len(pairs):
+            raise NotImplementedError("pair-based construction (utils/common.py:267-290) is not part of the inference path")
         self.body_parts = {}
-        for pair in pairs:
-            self.add_pair(pair)
         self.score = 0.0
 
-    @staticmethod
-    def _get_uidx(part_idx, idx):
-        return "%d-%d" % (part_idx, idx)
-
-    def add_pair(self, pair):
-        self.pairs.append(pair)
-        for part_idx, idx, coord, score in ((pair.part_idx1, pair.idx1, pair.coord1, pair.score),
-                                            (pair.part_idx2, pair.idx2, pair.coord2, pair.score)):
-            uid = Human._get_uidx(part_idx, idx)
-            self.body_parts[part_idx] = BodyPart(uid, part_idx, coord[0], coord[1], score)
-            self.uidx_list.add(uid)
-
-    def part_count(self):
-        return len(self.body_parts.keys())
-
-    def get_max_score(self):
-        return max(x.score for _, x in self.body_parts.items())
-
-    def __str__(self):
-        return " ".join(str(x) for x in self.body_parts.values())
-
-    __repr__ = __str__
+    def __repr__(self):
+        return f"Human(score {self.score:.3f}, parts {sorted(self.body_parts)})"

@@ -8,6 +8,13 @@ All three run on the GPU (pre-processing kernel -> model -> pp_flip_average / pp
 inputs/outputs the reference's signatures prescribe.  For throughput use posepaf.pipeline.PosePipeline, which keeps the
 network output in HBM and never builds these intermediate arrays.
 
+    predict(image, model, test_cfg, model_cfg, path, flip_avg=True, config=None) -> (heatmap_avg, paf_avg)  :180-283
+    find_peaks(heatmap_avg, test_cfg) -> list[18] of [(x, y, score, id), ...]                               :286-321
+
+the original (non-refactored) path of evaluate.py:81-84 at IMAGE resolution, thin callers of
+posepaf.original_path.OriginalPathProcessor (bicubic x4, crop, resize to the image, float64 accumulation; 3x3 / >= thre1
+NMS + refine_centroid) -- all on the GPU.
+
     find_connections(all_peaks, paf_avg, img_height, test_cfg, joint2limb_pairs) -> (connected_limbs, special_limb)  :324-410
     find_humans(connected_limbs, special_limb, joint_list, test_cfg, joint2limb_pairs) -> (persons, candidates)     :413-600
 
@@ -94,6 +101,84 @@ def find_peaks_refactor(param, img):
     jl = _post(h, w).nms(net, flip=False, refine=False)[0]
     xy = (jl[jl[:, 4] == 0][:, :2] + 0.5) / sk.STRIDE - 0.5       # undo compute_resized_coords (:122-123), exact
     return np.rint(xy).astype(np.intp)
+
+
+_orig_cache = {}
+
+
+def _original(img_h, img_w):
+    """one OriginalPathProcessor (accumulators at image resolution) per image size"""
+    from posepaf.original_path import OriginalPathProcessor
+    key = (img_h, img_w)
+    if key not in _orig_cache:
+        hp = -(-img_h // sk.MAX_DOWNSAMPLE) * sk.MAX_DOWNSAMPLE // sk.STRIDE
+        wp = -(-img_w // sk.MAX_DOWNSAMPLE) * sk.MAX_DOWNSAMPLE // sk.STRIDE
+        from posepaf.api import PosePostProcessor
+        post = PosePostProcessor(max_batch=1, max_h=hp, max_w=wp, max_peaks_per_part=64)
+        _orig_cache[key] = OriginalPathProcessor(post, img_h, img_w, 1)
+    return _orig_cache[key]
+
+
+def predict(image, model, test_cfg, model_cfg, input_image_path, flip_avg=True, config=None):
+    """utils/parse_skeletons.py:180-283: BGR uint8 (H, W, 3) -> (heatmap_avg (H, W, 20), paf_avg (H, W, 30)) float64 at IMAGE
+    resolution.  The scale list is [1.0], as the reference fixes it at :188 (its `scale_search` line :186 is dead);
+    `test_cfg["multiplier"]`, when present, overrides it (BASELINE config 5 uses 0.5 / 1.0 / 1.5).  rotation_search must be [0]."""
+    if any(a != 0 for a in test_cfg.get("rotation_search", [0.0])):
+        raise NotImplementedError("rotation_search != 0 is not supported (the reference's default is 0)")
+    from posepaf.original_path import resize_images_u8
+    img_h, img_w = image.shape[:2]
+    proc = _original(img_h, img_w)
+    dev = next(model.parameters()).device
+    dtype = next(model.parameters()).dtype
+    dtype = dtype if dtype in (torch.float16, torch.float32) else torch.float32
+    img = torch.from_numpy(np.ascontiguousarray(image)).to(dev)[None]
+    multiplier = [float(m) for m in test_cfg.get("multiplier", [1.0])]
+    with torch.no_grad():
+        proc.reset()
+        for scale in multiplier:
+            scaled = resize_images_u8(img, scale)                          # cv2.resize(image, fx=scale), :204
+            sh, sw = scaled.shape[1:3]
+            x = preprocess_batch(scaled, True, dtype)                      # pad to /64 with 128, /255, mirror (:206-226)
+            out = model(x)
+            maps = (out[-1][0] if isinstance(out, (list, tuple)) else out).contiguous()
+            if maps.dtype not in (torch.float16, torch.float32):
+                maps = maps.float()
+            maps = maps.view(1, 2, sk.NUM_CH, maps.shape[-2], maps.shape[-1])
+            if not flip_avg:
+                maps = maps[:, :1].contiguous()                            # :236-237 the un-mirrored sample alone
+            proc.accumulate(maps, x.shape[1] - sh, x.shape[2] - sw, len(multiplier), flip=bool(flip_avg))
+    heat = proc.heat_acc[0].permute(1, 2, 0).contiguous().cpu().numpy()
+    paf = proc.paf_acc[0].permute(1, 2, 0).contiguous().cpu().numpy()
+    return heat, paf
+
+
+def find_peaks(heatmap_avg, test_cfg):
+    """utils/parse_skeletons.py:286-321: (H, W, >=18) maps at image resolution -> list over the 18 parts of
+    [(x, y, score, id), ...]: 3x3 / >= thre1 NMS (util.keypoint_heatmap_nms) in np.nonzero order, util.refine_centroid with
+    radius 2 (x / y fractional, score = box mean), ids running across parts."""
+    if int(test_cfg.get("offset_radius", 2)) != 2:
+        raise NotImplementedError("offset_radius is fixed at 2 (utils/config:26)")
+    hm = np.asarray(heatmap_avg)
+    if hm.ndim != 3 or hm.shape[2] < NUM_KEYPOINTS:
+        raise ValueError("heatmap_avg must be (H, W, >=18)")
+    H, W = hm.shape[:2]
+    proc = _original(H, W)
+    with torch.no_grad():
+        proc.reset()
+        # the kernel casts the float64 accumulator to float32 on read, like heatmap_avg.astype(np.float32) at :290
+        proc.heat_acc[0, :NUM_KEYPOINTS] = torch.from_numpy(np.ascontiguousarray(hm[:, :, :NUM_KEYPOINTS].transpose(2, 0, 1)))\
+            .to(proc.heat_acc.device, torch.float64)
+        proc.finish(1, float(test_cfg.get("thre1", 0.1)))
+    counts = proc.post.read_part_counts(0)
+    if (counts > proc.post.maxp).any():
+        raise _lib.PosePafError(f"more than {proc.post.maxp} peaks in one keypoint channel: refused, not truncated")
+    rows = proc.peaks64[0].cpu().numpy()                                   # (18, maxp, 4) float64 [x, y, score, -]
+    all_peaks, pid = [], 0
+    for part in range(NUM_KEYPOINTS):
+        n = int(counts[part])
+        all_peaks.append([(float(r[0]), float(r[1]), float(r[2]), pid + i) for i, r in enumerate(rows[part, :n])])
+        pid += n
+    return all_peaks
 
 
 _ini = sk.default_test_cfg()

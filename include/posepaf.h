@@ -129,9 +129,10 @@ PP_API int pp_nms_batch(pp_ctx *ctx, int batch, const void *net_out_dev, int dty
 PP_API int pp_nms_batch_ex(pp_ctx *ctx, int batch, const void *net_out_dev, int dtype, int h, int w, int flip, int nms_mode,
                            float threshold, int refine_mode, float *peaks_dev, int *counts_dev, void *stream);
 
-/* Measurement aid: runs the three kernels of pp_process_batch `iters` times EACH on `stream`, bracketed by HIP
+/* Measurement aid: runs the kernels of pp_process_batch `iters` times EACH on `stream`, bracketed by HIP
  * events on that stream, and returns the average duration of one launch in milliseconds:
- * ms_out[0] = k_heat_peaks, ms_out[1] = k_limb_connect, ms_out[2] = k_assemble.  Blocking. */
+ * ms_out[0] = k_heat_peaks, ms_out[1] = k_limb_connect, ms_out[2] = k_assemble, ms_out[3] = the whole chain as
+ * pp_process_batch enqueues it (all launches back to back).  ms_out must hold 4 floats.  Blocking. */
 PP_API int pp_time_kernels(pp_ctx *ctx, int batch, const void *net_out_dev, int dtype, int h, int w, int flip,
                            int min_img_size, int iters, float *ms_out, void *stream);
 
@@ -201,6 +202,14 @@ PP_API int pp_debug_set_stamps(long long *stamps_dev);
 PP_API int pp_read_peaks(pp_ctx *ctx, int image, float *joint_list_host, int max_rows, int *n_rows);
 /* connections of one limb of one image, rows {cid1, cid2, score, length} (pafprocess.h:60-67) */
 PP_API int pp_read_connections(pp_ctx *ctx, int image, int limb, float *rows_host, int max_rows, int *n_rows);
+/* number of peaks found in every keypoint channel of one image (counts[18]; may exceed max_peaks_per_part: the true count) */
+PP_API int pp_read_part_counts(pp_ctx *ctx, int image, int *counts_host);
+/* number of accepted connections of every limb of one image (counts[30]); valid after either rule set (C++ or Python twins) */
+PP_API int pp_read_connection_counts(pp_ctx *ctx, int image, int *counts_host);
+/* Diagnostics: the raw per-workgroup status words of one image, flags[48] = 18 part words (peak kernels) then 30 limb words
+ * (limb kernels); pp_record.status is their OR plus the assembly's own flags.  Each word is plainly stored by its
+ * workgroup on every launch; none is ever memset or accumulated. */
+PP_API int pp_debug_read_flags(pp_ctx *ctx, int image, uint32_t *flags_host);
 /* device -> host copy of `batch` records, then synchronises the stream */
 PP_API int pp_read_records(pp_ctx *ctx, const pp_record *records_dev, pp_record *records_host, int batch, void *stream);
 
