@@ -724,7 +724,8 @@ def test_config2_forward_plus_nms_batch1_at_512(torch_cuda, oracle):
     maps = pipe.forward_maps(img)
     assert maps.shape == (1, 2, 50, 128, 128) and torch.isfinite(maps).all()
     inject = torch.from_numpy(synth.make_net_output(7, 321, dtype=np.float16)).cuda()[None]
-    maps = (maps + inject).contiguous()
+    amp = maps.float().abs().max().item()           # random weights: O(1) ripple, no structure
+    maps = torch.addcmul(inject, maps, torch.tensor(0.02 / amp, dtype=torch.float16, device="cuda")).contiguous()   # ripple <= 0.02
     for refine in (True, False):
         got = post.nms(maps, flip=True, refine=refine)[0]
         heat, _ = oracle.flip_average(maps[0].cpu().numpy())
@@ -736,7 +737,7 @@ def test_config2_forward_plus_nms_batch1_at_512(torch_cuda, oracle):
 
 def test_fp16_fused_forward_and_fp32_module_find_the_same_people(torch_cuda):
     """Scene-level check of the fp16 forward: the SAME image through the fused fp16 model and through the checkpoint-
-    compatible fp32 nn.Module, each output added (amplitude capped at 0.05, below the peak threshold) to the same clean synthetic scene, then the
+    compatible fp32 nn.Module, each output scaled to an amplitude of 0.05 (below the peak threshold) and added to the same clean synthetic scene, then the
     full HIP post-processing.  The two runs must find the same people: equal counts, equal part sets per person, joint
     coordinates within one feature-map cell (4 px; the x4 refinement arg-max may move by a pixel under fp16 noise)."""
     from config.config import GetConfig, TrainingOpt
@@ -756,8 +757,8 @@ def test_fp16_fused_forward_and_fp32_module_find_the_same_people(torch_cuda):
         fused = FusedIMHN.from_network(net).eval().cuda().half().to(memory_format=torch.channels_last)
         out16 = fused(preprocess_batch(img, True, torch.float16)).float()
     amp = out32.abs().max().item()
-    assert 0.0 < amp < 0.5
-    k = min(1.0, 0.05 / amp)          # keep the network's own ripple below the 0.1 peak threshold: no spurious peaks
+    assert amp > 0.0
+    k = 0.05 / amp                    # the network's own ripple scaled to 0.05: below the 0.1 peak threshold, no spurious peaks
     out32, out16 = out32 * k, out16 * k
     post = PosePostProcessor(max_batch=1, max_h=64, max_w=64, max_peaks_per_part=64)
     people = 0
@@ -809,7 +810,10 @@ def test_reference_named_original_path_functions(torch_cuda, oracle):
     rows = oracle.find_peaks_original(hs, 0.1)
     assert len(got) == 18 and sum(len(g) for g in got) == len(rows) > 30
     flat = np.array([r for part in got for r in part], np.float64).reshape(-1, 4)
-    assert np.allclose(flat[:, :3], rows[:, :3], rtol=0, atol=1e-9)
+    assert np.allclose(flat[:, :2], rows[:, :2], rtol=0, atol=1e-9)
+    # score = box.mean() of a float32 box: a float32 reduction in NumPy; the kernel rounds the float64 mean to float32, the
+    # oracle keeps the float64 mean (oracle/posepaf_oracle.c:843-845): equal to float32 rounding, tolerance 1e-6
+    assert np.allclose(flat[:, 2], rows[:, 2], rtol=0, atol=1e-6)
     assert np.array_equal(flat[:, 3], np.arange(len(rows)))
     parts = np.concatenate([[k] * len(g) for k, g in enumerate(got)])
     assert np.array_equal(parts, rows[:, 4].astype(int))
