@@ -341,8 +341,9 @@ class GpuEngine:
             return out
         ms = self.post.time_kernels(self.inject, IMG, True, iters=20)
         # algorithmic bytes per launch: every flip sample of every channel the kernel consumes, fp16, once
-        alg = {"k_heat_peaks": B * 18 * 2 * FEAT * FEAT * 2, "k_limb_connect": B * 30 * 2 * FEAT * FEAT * 2,
-               "k_assemble": B * 40960}                       # peaks + connections + record of one image: <= 40 KB
+        # the chain is two launches: k_heat_peaks (+ image ordering) and k_limb_connect (+ the person assembly by each image's
+        # last limb workgroup); k_assemble_wave in kernel_ms is the assembly alone as its own launch (diagnostic only)
+        alg = {"k_heat_peaks": B * 18 * 2 * FEAT * FEAT * 2, "k_limb_connect": B * 30 * 2 * FEAT * FEAT * 2}
         dom = max(alg, key=lambda k: ms[k])
         chain_bytes = sum(alg.values())
         achieved = alg[dom] / (ms[dom] * 1e-3) / 1e9

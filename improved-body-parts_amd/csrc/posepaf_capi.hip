@@ -22,6 +22,10 @@ struct pp_ctx {
     int *d_counts = nullptr;      // [max_batch][18]
     float4 *d_conns = nullptr;    // [max_batch][30][maxp] (cid1 bits, cid2 bits, score, length)
     int *d_conn_counts = nullptr; // [max_batch][30]
+    float4 *d_conn_aux = nullptr; // [max_batch][30][maxp] (peak id 1, peak id 2, peak score 1, peak score 2): K_B -> assembly
+    int *d_sync = nullptr;        // [2 * max_batch + 16]: image order [max_batch] | per-image arrival tickets [max_batch] | K_A's
+                                  // grid-wide ticket; zeroed ONCE here, re-armed by the kernels themselves (no memset node)
+    int mode = 0;                 // pp_debug_set_mode
     unsigned *d_status = nullptr; // [max_batch][48] flag words, one per producing workgroup (posepaf_kernels.hip or_flags)
     void *d_conns_py = nullptr;   // [max_batch][30][maxp] double4 (src, dst, score, length): Python-twin path
     double *d_persons = nullptr;  // [128][40] raw person table of the Python-twin host form
@@ -59,6 +63,8 @@ void free_ctx(pp_ctx *c) {
     (void)hipFree(c->d_counts);
     (void)hipFree(c->d_conns);
     (void)hipFree(c->d_conn_counts);
+    (void)hipFree(c->d_conn_aux);
+    (void)hipFree(c->d_sync);
     (void)hipFree(c->d_status);
     (void)hipFree(c->d_conns_py);
     (void)hipFree(c->d_persons);
@@ -124,6 +130,9 @@ int pp_create(pp_ctx **out, int device, int max_batch, int max_h, int max_w, int
     if (e == hipSuccess) e = hipMalloc(&c->d_counts, B * PP_NUM_PART * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&c->d_conns, B * PP_NUM_LIMB * c->maxp * sizeof(float4));
     if (e == hipSuccess) e = hipMalloc(&c->d_conn_counts, B * PP_NUM_LIMB * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&c->d_conn_aux, B * PP_NUM_LIMB * c->maxp * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc(&c->d_sync, (2 * B + 16) * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(c->d_sync, 0, (2 * B + 16) * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&c->d_conns_py, B * PP_NUM_LIMB * c->maxp * 32);
     if (e == hipSuccess) e = hipMalloc(&c->d_persons, 128 * 40 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&c->d_npersons, sizeof(int));
@@ -149,6 +158,12 @@ int pp_destroy(pp_ctx *ctx) {
 
 int pp_last_hip_error(const pp_ctx *ctx) { return ctx ? ctx->hip_err : 0; }
 
+int pp_debug_set_mode(pp_ctx *ctx, int mode) {
+    if (!ctx || mode < 0 || mode > 2) return PP_ERR_BAD_ARG;
+    ctx->mode = mode;
+    return PP_OK;
+}
+
 int pp_debug_set_stamps(long long *stamps_dev) {
     return pp::set_stamp_buffer(stamps_dev) == hipSuccess ? PP_OK : PP_ERR_HIP;
 }
@@ -168,7 +183,7 @@ int pp_nms_batch_ex(pp_ctx *ctx, int batch, const void *net_out_dev, int dtype, 
     float4 *pk = peaks_dev ? reinterpret_cast<float4 *>(peaks_dev) : ctx->d_peaks;
     int *cn = counts_dev ? counts_dev : ctx->d_counts;
     PP_HIP(ctx, pp::launch_heat_peaks(net_out_dev, dtype, batch, flip ? 2 : 1, h, w, flip, refine, nms_mode, threshold,
-                                      ctx->maxp, pk, cn, ctx->d_status, st));
+                                      ctx->maxp, pk, cn, ctx->d_status, nullptr, nullptr, st));
     ctx->last_stream = st;
     ctx->last_batch = batch;
     ctx->last_peaks = pk;
@@ -184,13 +199,20 @@ int pp_process_batch(pp_ctx *ctx, int batch, const void *net_out_dev, int dtype,
     hipStream_t st = static_cast<hipStream_t>(stream);
     pp_record *rec = records_dev ? records_dev : ctx->d_records;
     const int ns = flip ? 2 : 1;
+    // two launches: K_A (peaks; its last workgroup orders the images by load), K_B (limb scoring + matching; the last limb
+    // workgroup of each image assembles it).  ctx->mode: 0 as described, 1 = K_B and the assembly as separate launches,
+    // 2 = fused without the load ordering (A/B measurements, pp_debug_set_mode).
+    int *order = ctx->d_sync, *arrive = ctx->d_sync + ctx->max_batch, *arrive_all = ctx->d_sync + 2 * ctx->max_batch;
+    const bool sorted = ctx->mode == 0 && pp::heat_peaks_sorts(dtype, batch, h, w, ctx->maxp);
     PP_HIP(ctx, pp::launch_heat_peaks(net_out_dev, dtype, batch, ns, h, w, flip, 1, 0, 0.1f, ctx->maxp, ctx->d_peaks,
-                                      ctx->d_counts, ctx->d_status, st));
+                                      ctx->d_counts, ctx->d_status, sorted ? order : nullptr, sorted ? arrive_all : nullptr, st));
     PP_HIP(ctx, pp::launch_limb_connect(net_out_dev, dtype, batch, ns, h, w, flip, ctx->maxp, ctx->cap, min_img_size,
-                                        min_img_size_dev, ctx->d_peaks, ctx->d_counts, ctx->d_conns, ctx->d_conn_counts,
-                                        ctx->d_status, st));
-    PP_HIP(ctx, pp::launch_assemble(batch, ctx->maxp, 0, ctx->d_peaks, ctx->d_counts, ctx->d_conns, ctx->d_conn_counts,
-                                    ctx->d_status, 0, rec, st));
+                                        min_img_size_dev, ctx->d_peaks, ctx->d_counts, ctx->d_conns, ctx->d_conn_aux,
+                                        ctx->d_conn_counts, ctx->d_status, sorted ? order : nullptr,
+                                        ctx->mode == 1 ? nullptr : arrive, rec, st));
+    if (ctx->mode == 1)
+        PP_HIP(ctx, pp::launch_assemble_wave(batch, ctx->maxp, ctx->d_peaks, ctx->d_counts, ctx->d_conns, ctx->d_conn_aux,
+                                             ctx->d_conn_counts, ctx->d_status, rec, st));
     ctx->last_stream = st;
     ctx->last_batch = batch;
     ctx->last_peaks = ctx->d_peaks;
@@ -211,7 +233,7 @@ int pp_process_batch_py(pp_ctx *ctx, int batch, const void *net_out_dev, int dty
     pp_record *rec = records_dev ? records_dev : ctx->d_records;
     const int ns = flip ? 2 : 1;
     PP_HIP(ctx, pp::launch_heat_peaks(net_out_dev, dtype, batch, ns, h, w, flip, 1, 0, 0.1f, ctx->maxp, ctx->d_peaks,
-                                      ctx->d_counts, ctx->d_status, st));
+                                      ctx->d_counts, ctx->d_status, nullptr, nullptr, st));
     PP_HIP(ctx, pp::launch_limb_connect_py(net_out_dev, dtype, batch, ns, h, w, flip, ctx->maxp, ctx->cap, img_height,
                                            img_height_dev, ctx->d_peaks, ctx->d_counts, ctx->d_conns_py, ctx->d_conn_counts,
                                            ctx->d_status, st));
@@ -231,6 +253,8 @@ int pp_time_kernels(pp_ctx *ctx, int batch, const void *net_out_dev, int dtype, 
     if (!net_out_dev || !ms_out || iters <= 0) return PP_ERR_BAD_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int ns = flip ? 2 : 1;
+    int *order = ctx->d_sync, *arrive = ctx->d_sync + ctx->max_batch, *arrive_all = ctx->d_sync + 2 * ctx->max_batch;
+    const bool sorted = ctx->mode == 0 && pp::heat_peaks_sorts(dtype, batch, h, w, ctx->maxp);
     hipEvent_t e0, e1;
     PP_HIP(ctx, hipEventCreate(&e0));
     PP_HIP(ctx, hipEventCreate(&e1));
@@ -243,16 +267,19 @@ int pp_time_kernels(pp_ctx *ctx, int batch, const void *net_out_dev, int dtype, 
             if (k == 3) {  // the whole chain, back to back, as pp_process_batch enqueues it
                 rc = pp_process_batch(ctx, batch, net_out_dev, dtype, h, w, flip, min_img_size, nullptr, nullptr, st);
                 if (rc != PP_OK) return rc;
-            } else if (k == 0)
+            } else if (k == 0) {
                 PP_HIP(ctx, pp::launch_heat_peaks(net_out_dev, dtype, batch, ns, h, w, flip, 1, 0, 0.1f, ctx->maxp,
-                                                  ctx->d_peaks, ctx->d_counts, ctx->d_status, st));
-            else if (k == 1)
+                                                  ctx->d_peaks, ctx->d_counts, ctx->d_status, sorted ? order : nullptr,
+                                                  sorted ? arrive_all : nullptr, st));
+            } else if (k == 1) {  // limb scoring + matching with the assembly tail (the product's second launch)
                 PP_HIP(ctx, pp::launch_limb_connect(net_out_dev, dtype, batch, ns, h, w, flip, ctx->maxp, ctx->cap,
                                                     min_img_size, nullptr, ctx->d_peaks, ctx->d_counts, ctx->d_conns,
-                                                    ctx->d_conn_counts, ctx->d_status, st));
-            else
-                PP_HIP(ctx, pp::launch_assemble(batch, ctx->maxp, 0, ctx->d_peaks, ctx->d_counts, ctx->d_conns,
-                                                ctx->d_conn_counts, ctx->d_status, 0, ctx->d_records, st));
+                                                    ctx->d_conn_aux, ctx->d_conn_counts, ctx->d_status,
+                                                    sorted ? order : nullptr, arrive, ctx->d_records, st));
+            } else {  // the assembly alone, one wave per image, as its own launch (diagnostic)
+                PP_HIP(ctx, pp::launch_assemble_wave(batch, ctx->maxp, ctx->d_peaks, ctx->d_counts, ctx->d_conns,
+                                                     ctx->d_conn_aux, ctx->d_conn_counts, ctx->d_status, ctx->d_records, st));
+            }
         }
         PP_HIP(ctx, hipEventRecord(e1, st));
         PP_HIP(ctx, hipEventSynchronize(e1));

@@ -21,13 +21,20 @@ size_t lds_bytes_limb(int elem, int h, int w, int maxp, int cap);
 size_t lds_bytes_limb_hwc(int maxp, int cap);
 size_t lds_bytes_assemble(int maxp);
 
+// order / arrive_all (both or neither): K_A's last workgroup writes the images sorted by matching load into order[batch]
 hipError_t launch_heat_peaks(const void *net, int dtype, int batch, int n_samples, int h, int w, int flip, int refine,
-                             int nms_mode, float thr, int maxp, float4 *peaks, int *counts, unsigned *status,
-                             hipStream_t stream);
+                             int nms_mode, float thr, int maxp, float4 *peaks, int *counts, unsigned *status, int *order,
+                             int *arrive_all, hipStream_t stream);
+bool heat_peaks_sorts(int dtype, int batch, int h, int w, int maxp);
+// arrive != NULL: fused form, the last limb workgroup of each image assembles it into records (arrive[batch] zeroed once at
+// create, re-armed by the kernel); arrive == NULL: connections only (launch_assemble_wave follows).  order may be NULL.
 hipError_t launch_limb_connect(const void *net, int dtype, int batch, int n_samples, int h, int w, int flip, int maxp,
                                int cap, int min_img_size, const int *min_img_size_dev, const float4 *peaks,
-                               const int *counts, float4 *conns, int *conn_counts, unsigned *status,
-                               hipStream_t stream);
+                               const int *counts, float4 *conns, float4 *aux, int *conn_counts, unsigned *status,
+                               const int *order, int *arrive, pp_record *records, hipStream_t stream);
+hipError_t launch_assemble_wave(int batch, int maxp, const float4 *peaks, const int *counts, const float4 *conns,
+                                const float4 *aux, const int *conn_counts, const unsigned *status, pp_record *records,
+                                hipStream_t stream);
 hipError_t launch_limb_connect_hwc(const float *paf, int H, int W, int C, int maxp, int cap, int min_img_size,
                                    const float4 *peaks, const int *counts, float4 *conns, int *conn_counts,
                                    unsigned *status, hipStream_t stream);

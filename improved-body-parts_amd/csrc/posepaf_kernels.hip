@@ -32,6 +32,8 @@ __device__ const int8_t d_limb_pairs[PP_NUM_LIMB][2] = {
     {1, 0},   {1, 14},  {1, 15},  {1, 16},  {1, 17},  {0, 14},  {0, 15},  {14, 16}, {15, 17}, {1, 2},
     {2, 3},   {3, 4},   {1, 5},   {5, 6},   {6, 7},   {1, 8},   {8, 9},   {9, 10},  {1, 11},  {11, 12},
     {12, 13}, {0, 2},   {0, 5},   {2, 8},   {8, 12},  {5, 11},  {11, 9},  {16, 2},  {17, 5},  {8, 11}};
+constexpr int kLimbA[PP_NUM_LIMB] = {1, 1, 1, 1, 1, 0, 0, 14, 15, 1, 2, 3, 1, 5, 6, 1, 8, 9, 1, 11, 12, 0, 0, 2, 8, 5, 11, 16, 17, 8};
+constexpr int kLimbB[PP_NUM_LIMB] = {0, 14, 15, 16, 17, 14, 15, 16, 17, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 2, 5, 8, 12, 11, 9, 2, 5, 11};
 // config/config.py:150-152
 __device__ const int8_t d_flip_heat_ord[PP_NUM_HEAT] = {0, 1, 5, 6, 7, 2, 3, 4, 11, 12, 13, 8, 9, 10, 15, 14, 17, 16, 18, 19};
 __device__ const int8_t d_flip_paf_ord[PP_NUM_LIMB] = {0,  2,  1,  4,  3,  6,  5,  8,  7,  12, 13, 14, 9,  10, 11,
@@ -241,8 +243,8 @@ __device__ __forceinline__ float bicubic4_at(const T *smap, int w, int x0, int y
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_heat_peaks(const T *__restrict__ net, int n_samples, int h, int w,
                                                          int flip, int refine, int nms_mode, float thr, int maxp,
-                                                         float4 *__restrict__ peaks, int *__restrict__ counts,
-                                                         unsigned *__restrict__ status) {
+                                                         float4 *__restrict__ peaks, int *counts,
+                                                         unsigned *__restrict__ status, int *order, int *arrive_all) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int part = blockIdx.x, img = blockIdx.y;
     const int npix = h * w;
@@ -497,11 +499,50 @@ __global__ __launch_bounds__(kThreads) void k_heat_peaks(const T *__restrict__ n
         if (lane == 0) out[p] = make_float4(ox, oy, score, 0.0f);
     }
     if (threadIdx.x == 0) {
-        counts[img * PP_NUM_PART + part] = total;
+        // write-through (sc1) so that the sorting workgroup below reads this launch's count; correctness never depends on it
+        __hip_atomic_store(counts + img * PP_NUM_PART + part, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         status[img * kFlagWords + part] = total > maxp ? PP_ST_PEAK_OVERFLOW : 0u;  // plain store, every launch
     }
     __syncthreads();
     stamp(stamps, wg, 3);
+    if (!order) return;
+    // ---- the LAST workgroup of the grid orders the images by estimated matching load (sum over limbs of nA * nB), heaviest
+    // first, for K_B's dispatch.  A stale count can only make the order worse, never wrong: the ranks below always form a
+    // permutation of 0..B-1 (ties broken by index) because they are computed from ONE consistent copy in LDS.
+    __shared__ int s_sorter;
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int t = __hip_atomic_fetch_add(arrive_all, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = t == (int)(gridDim.x * gridDim.y) - 1;
+        if (last) __hip_atomic_store(arrive_all, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
+        s_sorter = last;
+    }
+    __syncthreads();
+    if (!s_sorter) return;
+    const int B = gridDim.y;
+    int *s_w = reinterpret_cast<int *>(lds_raw);  // the map is no longer needed (the host checked that B ints fit)
+    for (int i = threadIdx.x; i < B; i += kThreads) {
+        int c[PP_NUM_PART];
+#pragma unroll
+        for (int p = 0; p < PP_NUM_PART; p++) {
+            const int v = __hip_atomic_load(counts + i * PP_NUM_PART + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            c[p] = v < maxp ? v : maxp;
+        }
+        int wsum = 0;
+#pragma unroll
+        for (int l = 0; l < PP_NUM_LIMB; l++) wsum += c[kLimbA[l]] * c[kLimbB[l]];
+        s_w[i] = wsum;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < B; i += kThreads) {
+        const int wi = s_w[i];
+        int rank = 0;
+        for (int j = 0; j < B; j++) {
+            const int wj = s_w[j];
+            rank += (wj > wi) || (wj == wi && j < i);
+        }
+        order[rank] = i;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ K_B
@@ -819,7 +860,8 @@ __device__ inline LimbLds carve_limb_lds(unsigned char *p, int maxp, int cap) {
 template <typename Sampler>
 __device__ void connect_limb(const Sampler &smp, const LimbLds &L, int nA, int nB, int cap, int maxp, int min_img_size,
                              float4 *__restrict__ conn_out, int *__restrict__ conn_count,
-                             unsigned *__restrict__ status_word, long long *stamps = nullptr, int wg = 0) {
+                             unsigned *__restrict__ status_word, long long *stamps = nullptr, int wg = 0,
+                             float4 *__restrict__ aux_out = nullptr, int offA = 0, int offB = 0) {
     __shared__ int s_wcnt[2][kWaves];
     __shared__ int s_stack[3 * kSortStack];
     __shared__ int s_oob;
@@ -1071,8 +1113,12 @@ __device__ void connect_limb(const Sampler &smp, const LimbLds &L, int nA, int n
         }
         if (acc) {
             const unsigned idx = L.c_idx[t];
-            conn_out[ncn + before + __popcll(m & lanemask_lt())] =
-                make_float4(__int_as_float((int)(idx & 0xffffu)), __int_as_float((int)(idx >> 16)), L.c_score[t], L.c_len[t]);
+            const int ia = (int)(idx & 0xffffu), ib = (int)(idx >> 16);
+            const int o = ncn + before + __popcll(m & lanemask_lt());
+            conn_out[o] = make_float4(__int_as_float(ia), __int_as_float(ib), L.c_score[t], L.c_len[t]);
+            // what the assembly needs besides: the two peaks' ids (position in the part-ordered peak line,
+            // pafprocess.cpp:34, :43-48) and their scores (pl[id].score, :162, :266)
+            if (aux_out) aux_out[o] = make_float4(__int_as_float(offA + ia), __int_as_float(offB + ib), L.as[ia], L.bs[ib]);
         }
         ncn += all;
     }
@@ -1083,65 +1129,619 @@ __device__ void connect_limb(const Sampler &smp, const LimbLds &L, int nA, int n
     stamp(stamps, wg, 5);
 }
 
-// LDS layout (dynamic): [map h*w T][cubic 16 f32][LimbLds: 40*maxp + 28*cap bytes]
+// ------------------------------------------------------------------------------------------------ K_C, wave form
+// pafprocess.cpp:132-285 for ONE image by ONE wave -- the form the batched path uses, either as the tail of K_B (the last
+// limb workgroup of an image to finish runs it: k_limb_connect) or as a kernel of its own (k_assemble_wave: timing,
+// diagnostics).  Same results as k_assemble above, different mechanics:
+//   * STABLE SLOTS.  A skeleton is born into the next free slot and never moves; `skeletons.erase` (:228) only marks the
+//     slot dead.  The reference's vector order is the birth order of the live skeletons, so "first match" / "second match"
+//     of the scan (:143-150) are the lowest / second-lowest matching slot and the output order is slot order.  No row shifts.
+//     (Slots run out only after 256 BIRTHS; the table is then compacted, order preserved, and only more than 256 LIVE
+//     skeletons raise PP_ST_SKEL_OVERFLOW, as before.)
+//   * The table is part-major, sk[p][slot]: lane s reads/writes column s of a row without bank conflicts.  Per limb every
+//     lane caches the six words of "its" skeletons that a limb can touch (ids of the limb's two parts, the part-2 score,
+//     count, total, longest limb) in registers; updates go to the registers and write through to LDS.
+//   * Classification of a limb's connections (<= 64 per pass) with two small tables instead of a scan per connection:
+//     connection lanes publish "end point -> connection", skeleton lanes look their two peaks up and count themselves into
+//     cnt[connection] (= the reference's num_found, one per matching skeleton) and flag the connections that share a
+//     skeleton.  Connections with cnt <= 1 that share nothing are independent of every other connection of the limb
+//     (pairwise different end points): found-1 updates are applied by the owning skeleton lane, births by the connection
+//     lane, whole runs at once and in connection order; the others (two skeletons = possible merge, a shared skeleton, a
+//     peak held twice) go through the reference's scan one by one -- done on the cached registers with one ballot per 64
+//     slots, no LDS round trip.  A merge that ADDS two real ids in the limb's columns (the `id > 0` quirk, :200-226) makes
+//     an id the tables of this pass never saw: from there the pass continues one by one (hand-built test scene).
+//   * Connections arrive as two float4 per connection written by K_B: (rank1, rank2, score, length) and
+//     (peak id 1, peak id 2, peak score 1, peak score 2), so no peak table is needed before the records are written.
+constexpr int kSlots = 256;
+constexpr int kBanks = kSlots / 64;
+constexpr int kDeadId = -2;  // ids are >= -1 (and sums of those + 1): -2 never matches and never arises
+
+__host__ __device__ inline size_t assemble_wave_lds_bytes(int maxp) {
+    return (size_t)2 * 20 * kSlots * 4 + (size_t)2 * maxp * 4 + 2 * 64 * 4 + 32 * 4;
+}
+
+struct AsmWaveLds {
+    int *sk_id;    // [20][kSlots] rows 0..17 peak id per part (-1 empty, kDeadId erased), row 19 part count
+    float *sk_sc;  // [20][kSlots] rows 0..17 limb score per part, row 18 total score, row 19 longest limb
+    int *cb1, *cb2;  // [maxp] tag | connection lane, by end-point rank within the part
+    int *cnt, *conf;  // [64]
+    int *off;        // [19] flat peak id of the first peak of each part (+ total)
+};
+__device__ inline AsmWaveLds carve_asm_wave_lds(unsigned char *p, int maxp) {
+    AsmWaveLds A;
+    A.sk_id = reinterpret_cast<int *>(p);
+    A.sk_sc = reinterpret_cast<float *>(A.sk_id + 20 * kSlots);
+    A.cb1 = reinterpret_cast<int *>(A.sk_sc + 20 * kSlots);
+    A.cb2 = A.cb1 + maxp;
+    A.cnt = A.cb2 + maxp;
+    A.conf = A.cnt + 64;
+    A.off = A.conf + 64;
+    return A;
+}
+
+// value of lane `l` (wave-UNIFORM index) as a scalar: the results steer uniform control flow
+__device__ __forceinline__ int rl(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ float rlf(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+__device__ __forceinline__ void wave_lds_sync() {
+    // one wave: its LDS operations complete in issue order; only the compiler must not move them across this point
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// the six cached words of one skeleton slot for the current limb
+struct SkelCache {
+    int p1, p2, ct;
+    float s2, ln, tt;
+};
+
+// :152-180 on the cached skeleton (found exactly one); write-through.  Only the part-2 entry can change.
+__device__ __forceinline__ void apply_found1(SkelCache &k, const AsmWaveLds &A, int slot, int part2, int id2, float c_score,
+                                             float c_len, float ps2) {
+    const float len1 = k.ln;
+    const int min_len = (int)__fmul_rn(len1, 16.0f);  // :154 int truncation of length * LIMB_LENGTH_RATE
+    bool wr = false;
+    if (k.p2 == -1 && (float)min_len > c_len) {
+        k.ct += 1;
+        k.tt = __fadd_rn(k.tt, __fadd_rn(ps2, c_score));
+        wr = true;
+    } else if ((k.p2 != id2 && k.s2 <= c_score && (float)min_len > c_len) || (k.p2 == id2 && k.s2 <= c_score)) {
+        // :163-180 id/score are overwritten BEFORE the subtraction: total = (total - t) + t, t = pl[id2].score + conn.score
+        const float t = __fadd_rn(ps2, c_score);
+        k.tt = __fadd_rn(__fadd_rn(k.tt, -t), t);
+        wr = true;
+    }
+    if (wr) {
+        k.p2 = id2;
+        k.s2 = c_score;
+        k.ln = len1 < c_len ? c_len : len1;
+        A.sk_id[part2 * kSlots + slot] = k.p2;
+        A.sk_sc[part2 * kSlots + slot] = k.s2;
+        A.sk_id[19 * kSlots + slot] = k.ct;
+        A.sk_sc[19 * kSlots + slot] = k.ln;
+        A.sk_sc[18 * kSlots + slot] = k.tt;
+    }
+}
+
+__device__ __forceinline__ void load_cache(SkelCache &k, const AsmWaveLds &A, int slot, int part1, int part2, bool valid) {
+    k.p1 = valid ? A.sk_id[part1 * kSlots + slot] : kDeadId;
+    k.p2 = valid ? A.sk_id[part2 * kSlots + slot] : kDeadId;
+    k.s2 = valid ? A.sk_sc[part2 * kSlots + slot] : 0.0f;
+    k.ct = valid ? A.sk_id[19 * kSlots + slot] : 0;
+    k.ln = valid ? A.sk_sc[19 * kSlots + slot] : 0.0f;
+    k.tt = valid ? A.sk_sc[18 * kSlots + slot] : 0.0f;
+}
+
+// Executed by all 64 lanes of ONE wave (lane = threadIdx.x & 63); `lds` holds assemble_wave_lds_bytes(maxp) bytes that no
+// other wave touches.  conns / aux: [30][maxp] of this image; cc_g: its 30 connection counts; cnt_g: its 18 peak counts.
+__device__ __forceinline__ void assemble_image_wave(int img, int lane, int maxp, const float4 *__restrict__ pk_g, const int *__restrict__ cnt_g,
+                                    const float4 *__restrict__ conns, const float4 *__restrict__ aux,
+                                    const int *__restrict__ cc_g, const unsigned *__restrict__ flags,
+                                    pp_record *__restrict__ rec, unsigned char *lds, long long *stamps) {
+    const AsmWaveLds A = carve_asm_wave_lds(lds, maxp);
+    stamp(stamps, img, 0);
+    // ---- counts -> flat id offsets (pafprocess.cpp:43-48 flattens in part order); per-limb connection counts
+    int pc = lane < PP_NUM_PART ? cnt_g[lane] : 0;
+    int cc = lane < PP_NUM_LIMB ? cc_g[lane] : 0;
+    pc = pc < maxp ? pc : maxp;
+    cc = cc < maxp ? cc : maxp;
+    int inc = pc, cinc = cc;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+        const int t = __shfl_up(inc, d), ct = __shfl_up(cinc, d);
+        if (lane >= d) {
+            inc += t;
+            cinc += ct;
+        }
+    }
+    const int offv = inc - pc;  // lane p: flat id of part p's first peak
+    const int n_peaks = rl(inc, PP_NUM_PART - 1);
+    const int n_conn = rl(cinc, PP_NUM_LIMB - 1);
+    if (lane <= PP_NUM_PART) A.off[lane] = lane < PP_NUM_PART ? offv : n_peaks;
+    // first limb's connections on their way while the table is initialised
+    const int m0 = rl(cc, 0);
+    float4 pre_cn = make_float4(0.f, 0.f, 0.f, 0.f), pre_ax = pre_cn;
+    if (lane < m0) {
+        pre_cn = conns[lane];
+        pre_ax = aux[lane];
+    }
+    {  // every slot starts as an empty skeleton: ids -1, scores -1 (rows 18 / 19 are set at birth); lookup tables: tag 0
+        int4 *qi = reinterpret_cast<int4 *>(A.sk_id);
+        float4 *qf = reinterpret_cast<float4 *>(A.sk_sc);
+        const int4 mi = make_int4(-1, -1, -1, -1);
+        const float4 mf = make_float4(-1.0f, -1.0f, -1.0f, -1.0f);
+        for (int i = lane; i < 18 * kSlots / 4; i += 64) {
+            qi[i] = mi;
+            qf[i] = mf;
+        }
+        for (int i = lane; i < 2 * maxp; i += 64) A.cb1[i] = 0;
+    }
+    wave_lds_sync();
+    stamp(stamps, img, 1);
+
+    int nb = 0;  // slots used so far (uniform)
+    unsigned st = 0;
+    long long seq_conns = 0, seq_cycles = 0, odd_merges = 0;
+    SkelCache K[kBanks];
+    for (int limb = 0; limb < PP_NUM_LIMB; limb++) {
+        const int m = rl(cc, limb);
+        float4 cur_cn = pre_cn, cur_ax = pre_ax;
+        if (limb + 1 < PP_NUM_LIMB) {  // next limb's first 64 connections: in flight during this limb
+            const int mn = rl(cc, limb + 1);
+            if (lane < mn) {
+                pre_cn = conns[(size_t)(limb + 1) * maxp + lane];
+                pre_ax = aux[(size_t)(limb + 1) * maxp + lane];
+            }
+        }
+        if (m == 0) continue;
+        const int part1 = d_limb_pairs[limb][0], part2 = d_limb_pairs[limb][1];
+        const int off1 = rl(offv, part1), off2 = rl(offv, part2);
+        const int cnt1 = rl(pc, part1), cnt2 = rl(pc, part2);
+        for (int c0 = 0; c0 < m; c0 += 64) {  // passes of <= 64 connections (a second pass only with max_peaks_per_part > 64)
+            const int mc = m - c0 < 64 ? m - c0 : 64;
+            if (c0 > 0 && lane < mc) {
+                cur_cn = conns[(size_t)limb * maxp + c0 + lane];
+                cur_ax = aux[(size_t)limb * maxp + c0 + lane];
+            }
+            const bool have = lane < mc;
+            const int id1 = __float_as_int(cur_ax.x), id2 = __float_as_int(cur_ax.y);
+            const float c_score = cur_cn.z, c_len = cur_cn.w, ps1 = cur_ax.z, ps2 = cur_ax.w;
+
+            if (nb + mc > kSlots) {  // ---- out of slots: drop the erased ones, order preserved (rare)
+                bool alive[kBanks];
+                int newpos[kBanks];
+                int base = 0;
+#pragma unroll
+                for (int b = 0; b < kBanks; b++) {
+                    const int slot = b * 64 + lane;
+                    alive[b] = slot < nb && A.sk_id[slot] != kDeadId;
+                    const unsigned long long mk = __ballot(alive[b]);
+                    newpos[b] = base + __popcll(mk & lanemask_lt());
+                    base += __popcll(mk);
+                }
+#pragma unroll 1
+                for (int row = 0; row < 20; row++) {
+                    int vi[kBanks];
+                    float vf[kBanks];
+#pragma unroll
+                    for (int b = 0; b < kBanks; b++) {
+                        vi[b] = A.sk_id[row * kSlots + b * 64 + lane];
+                        vf[b] = A.sk_sc[row * kSlots + b * 64 + lane];
+                    }
+                    wave_lds_sync();
+#pragma unroll
+                    for (int b = 0; b < kBanks; b++)
+                        if (alive[b]) {
+                            A.sk_id[row * kSlots + newpos[b]] = vi[b];
+                            A.sk_sc[row * kSlots + newpos[b]] = vf[b];
+                        }
+                    wave_lds_sync();
+                    if (row < 18)
+#pragma unroll
+                        for (int b = 0; b < kBanks; b++) {
+                            const int slot = b * 64 + lane;
+                            if (slot >= base && slot < nb) {
+                                A.sk_id[row * kSlots + slot] = -1;
+                                A.sk_sc[row * kSlots + slot] = -1.0f;
+                            }
+                        }
+                }
+                wave_lds_sync();
+                nb = base;
+            }
+
+            // ---- 1. cache the words of every skeleton this limb can touch
+#pragma unroll
+            for (int b = 0; b < kBanks; b++)
+                if (b * 64 < nb) load_cache(K[b], A, b * 64 + lane, part1, part2, b * 64 + lane < nb);
+                else K[b].p1 = K[b].p2 = kDeadId;
+            // ---- 2. classification
+            const int tag = (2 * limb + (c0 ? 1 : 0) + 1) << 8;  // unique per pass; the tables never need re-zeroing
+            if (have) {
+                A.cb1[id1 - off1] = tag | lane;  // end points are pairwise different within a limb: no write conflicts
+                A.cb2[id2 - off2] = tag | lane;
+            }
+            A.cnt[lane] = 0;
+            A.conf[lane] = 0;
+            wave_lds_sync();
+            int myk[kBanks];
+#pragma unroll
+            for (int b = 0; b < kBanks; b++) {
+                myk[b] = -1;
+                if (b * 64 < nb) {
+                    const int r1 = K[b].p1 - off1, r2 = K[b].p2 - off2;  // erased / unused slots: negative
+                    int k1 = -1, k2 = -1;
+                    if (r1 >= 0 && r1 < cnt1) {
+                        const int v = A.cb1[r1];
+                        if ((v & ~0xff) == tag) k1 = v & 0xff;
+                    }
+                    if (r2 >= 0 && r2 < cnt2) {
+                        const int v = A.cb2[r2];
+                        if ((v & ~0xff) == tag) k2 = v & 0xff;
+                    }
+                    if (k1 >= 0) atomicAdd(&A.cnt[k1], 1);  // one count per matching SKELETON (:146-149)
+                    if (k2 >= 0 && k2 != k1) atomicAdd(&A.cnt[k2], 1);
+                    if (k1 >= 0 && k2 >= 0 && k1 != k2) {  // one skeleton, two connections: order matters
+                        A.conf[k1] = 1;
+                        A.conf[k2] = 1;
+                    } else {
+                        myk[b] = k1 >= 0 ? k1 : k2;
+                    }
+                }
+            }
+            wave_lds_sync();
+            const int nfound = have ? A.cnt[lane] : 0;
+            const bool conflict = have && (A.conf[lane] != 0 || nfound >= 2);
+            const bool isnew = have && nfound == 0;
+            unsigned long long confm = __ballot(conflict);
+            bool any_par = false;
+#pragma unroll
+            for (int b = 0; b < kBanks; b++) {
+                if (myk[b] >= 0 && ((confm >> myk[b]) & 1ull)) myk[b] = -1;  // its connection goes one by one
+                any_par |= myk[b] >= 0;
+            }
+            // connection words for the skeleton lanes that apply a found-1 update in a run
+            int f_id2[kBanks];
+            float f_cs[kBanks], f_cl[kBanks], f_ps2[kBanks];
+            if (__ballot(any_par)) {
+#pragma unroll
+                for (int b = 0; b < kBanks; b++) {
+                    const int src = myk[b] >= 0 ? myk[b] : lane;
+                    f_id2[b] = __shfl(id2, src);
+                    f_cs[b] = __shfl(c_score, src);
+                    f_cl[b] = __shfl(c_len, src);
+                    f_ps2[b] = __shfl(ps2, src);
+                }
+            }
+            // ---- 3. in connection order: maximal runs of independent connections in one step, the others one by one
+            int pos = 0;
+            while (pos < mc) {
+                const unsigned long long rest = confm >> pos;
+                int next = rest ? pos + __ffsll((long long)rest) - 1 : mc;
+                next = next < mc ? next : mc;
+                if (next > pos) {
+#pragma unroll
+                    for (int b = 0; b < kBanks; b++)
+                        if (myk[b] >= pos && myk[b] < next)
+                            apply_found1(K[b], A, b * 64 + lane, part2, f_id2[b], f_cs[b], f_cl[b], f_ps2[b]);
+                    const bool born = isnew && lane >= pos && lane < next;
+                    const unsigned long long mnew = __ballot(born);
+                    if (mnew) {  // :257-273 new skeletons, slots in connection order
+                        const int slot = nb + __popcll(mnew & lanemask_lt());
+                        if (born && slot < kSlots) {
+                            A.sk_id[part1 * kSlots + slot] = id1;
+                            A.sk_sc[part1 * kSlots + slot] = c_score;
+                            A.sk_id[part2 * kSlots + slot] = id2;
+                            A.sk_sc[part2 * kSlots + slot] = c_score;
+                            A.sk_id[19 * kSlots + slot] = 2;
+                            A.sk_sc[19 * kSlots + slot] = c_len;
+                            A.sk_sc[18 * kSlots + slot] = __fadd_rn(__fadd_rn(ps1, ps2), c_score);
+                        }
+                        nb += __popcll(mnew);
+                        if (nb > kSlots) {
+                            nb = kSlots;
+                            st |= PP_ST_SKEL_OVERFLOW;
+                        }
+                    }
+                }
+                if (next < mc) {  // ---- the reference's scan for connection `next`, on the cached registers
+                    const long long t0 = stamps ? (long long)clock64() : 0;
+                    const int u_id1 = rl(id1, next), u_id2 = rl(id2, next);
+                    const float u_cs = rlf(c_score, next), u_cl = rlf(c_len, next);
+                    const float u_ps1 = rlf(ps1, next), u_ps2 = rlf(ps2, next);
+                    int num_found = 0, idx1 = 0, idx2 = 0;
+#pragma unroll
+                    for (int b = 0; b < kBanks; b++) {
+                        if (b * 64 < nb) {
+                            unsigned long long mk = __ballot(K[b].p1 == u_id1 || K[b].p2 == u_id2);
+                            if (mk) {
+                                if (num_found == 0) {
+                                    idx1 = b * 64 + __ffsll((long long)mk) - 1;
+                                    const unsigned long long m2 = mk & (mk - 1);
+                                    if (m2) idx2 = b * 64 + __ffsll((long long)m2) - 1;
+                                } else if (num_found == 1) {
+                                    idx2 = b * 64 + __ffsll((long long)mk) - 1;
+                                }
+                                num_found += __popcll(mk);
+                            }
+                        }
+                    }
+                    if (num_found == 1) {
+#pragma unroll
+                        for (int b = 0; b < kBanks; b++)
+                            if ((idx1 >> 6) == b && (idx1 & 63) == lane) apply_found1(K[b], A, idx1, part2, u_id2, u_cs, u_cl, u_ps2);
+                    } else if (num_found == 2) {  // :182-256, one part per lane; LDS is current (write-through)
+                        wave_lds_sync();
+                        const bool isp = lane < PP_NUM_PART;
+                        const int a_i1 = isp ? A.sk_id[lane * kSlots + idx1] : -1, a_i2 = isp ? A.sk_id[lane * kSlots + idx2] : -1;
+                        const float a_f1 = isp ? A.sk_sc[lane * kSlots + idx1] : 0.0f, a_f2 = isp ? A.sk_sc[lane * kSlots + idx2] : 0.0f;
+                        const bool a1 = a_i1 > 0, a2 = a_i2 > 0;  // :200-201 id 0 counts as unassigned
+                        if (__ballot(a1 && a2) == 0) {
+                            // :203-214 running minima "min = (min == 0) ? v : min(v, min)": a plain minimum unless a value is exactly 0
+                            float min1, min2;
+                            if (__ballot((a1 && a_f1 == 0.0f) || (a2 && a_f2 == 0.0f))) {
+                                min1 = 0.0f;
+                                min2 = 0.0f;
+#pragma unroll 1
+                                for (int kp = 0; kp < PP_NUM_PART; kp++) {
+                                    const int i1 = rl(a_i1, kp), i2 = rl(a_i2, kp);
+                                    const float f1 = rlf(a_f1, kp), f2 = rlf(a_f2, kp);
+                                    if (i1 > 0) min1 = (min1 == 0.0f) ? f1 : (f1 < min1 ? f1 : min1);
+                                    if (i2 > 0) min2 = (min2 == 0.0f) ? f2 : (f2 < min2 ? f2 : min2);
+                                }
+                            } else {
+                                const float inf = __int_as_float(0x7f800000);
+                                min1 = a1 ? a_f1 : inf;
+                                min2 = a2 ? a_f2 : inf;
+#pragma unroll
+                                for (int d = 16; d >= 1; d >>= 1) {
+                                    min1 = fminf(min1, __shfl_xor(min1, d));
+                                    min2 = fminf(min2, __shfl_xor(min2, d));
+                                }
+                                min1 = rlf(min1, 0);
+                                min2 = rlf(min2, 0);
+                                if (min1 == inf) min1 = 0.0f;
+                                if (min2 == inf) min2 = 0.0f;
+                            }
+                            const float len1 = A.sk_sc[19 * kSlots + idx1];
+                            const int min_len = (int)__fmul_rn(len1, 16.0f);
+                            const float lim = __fmul_rn((min2 < min1 ? min2 : min1), 0.7f);  // :220
+                            if (u_cs >= lim || u_cl < (float)min_len) {                       // :221 OR
+                                // a limb column where BOTH rows hold an id gets their sum + 1: an id this pass's tables never saw
+                                const bool odd = __ballot((lane == part1 || lane == part2) && a_i1 >= 0 && a_i2 >= 0) != 0;
+                                const float tot = __fadd_rn(A.sk_sc[18 * kSlots + idx1], __fadd_rn(A.sk_sc[18 * kSlots + idx2], u_cs));
+                                const int cnt = A.sk_id[19 * kSlots + idx1] + A.sk_id[19 * kSlots + idx2];
+                                wave_lds_sync();
+                                if (isp) {
+                                    A.sk_id[lane * kSlots + idx1] = a_i1 + (a_i2 + 1);
+                                    A.sk_sc[lane * kSlots + idx1] = __fadd_rn(a_f1, __fadd_rn(a_f2, 1.0f));
+                                    A.sk_id[lane * kSlots + idx2] = kDeadId;  // skeletons.erase(begin + idx2), :228
+                                }
+                                if (lane == 0) {
+                                    A.sk_id[19 * kSlots + idx1] = cnt;
+                                    A.sk_sc[19 * kSlots + idx1] = len1 < u_cl ? u_cl : len1;
+                                    A.sk_sc[18 * kSlots + idx1] = tot;
+                                }
+                                wave_lds_sync();
+#pragma unroll
+                                for (int b = 0; b < kBanks; b++) {  // refresh the two owners' caches
+                                    if ((idx1 >> 6) == b && (idx1 & 63) == lane) load_cache(K[b], A, idx1, part1, part2, true);
+                                    if ((idx2 >> 6) == b && (idx2 & 63) == lane) K[b].p1 = K[b].p2 = kDeadId;
+                                }
+                                if (odd) {  // from here on every connection of this pass scans, as the reference does
+                                    confm |= next + 1 < 64 ? ~0ull << (next + 1) : 0ull;
+#pragma unroll
+                                    for (int b = 0; b < kBanks; b++) myk[b] = -1;
+                                    odd_merges++;
+                                }
+                            }
+                        }
+                    } else if (num_found == 0) {  // :257-273
+                        if (nb < kSlots) {
+                            if (lane == 0) {
+                                A.sk_id[part1 * kSlots + nb] = u_id1;
+                                A.sk_sc[part1 * kSlots + nb] = u_cs;
+                                A.sk_id[part2 * kSlots + nb] = u_id2;
+                                A.sk_sc[part2 * kSlots + nb] = u_cs;
+                                A.sk_id[19 * kSlots + nb] = 2;
+                                A.sk_sc[19 * kSlots + nb] = u_cl;
+                                A.sk_sc[18 * kSlots + nb] = __fadd_rn(__fadd_rn(u_ps1, u_ps2), u_cs);
+                            }
+                            nb++;
+                        } else {
+                            st |= PP_ST_SKEL_OVERFLOW;
+                        }
+                    }
+                    // num_found > 2: no action
+                    if (stamps) {
+                        seq_cycles += (long long)clock64() - t0;
+                        seq_conns++;
+                    }
+                }
+                pos = next + 1;
+            }
+        }
+    }
+    wave_lds_sync();
+    stamp(stamps, img, 2);
+    if (stamps && lane == 0) {
+        stamps[(size_t)img * 8 + 4] = seq_conns;
+        stamps[(size_t)img * 8 + 5] = seq_cycles;
+        stamps[(size_t)img * 8 + 6] = odd_merges;
+    }
+
+    // ---- prune (:278-282) + records; survivors in slot (= birth) order
+    int n_out = 0;
+#pragma unroll
+    for (int b = 0; b < kBanks; b++) {
+        if (b * 64 >= nb) break;
+        const int s = b * 64 + lane;
+        bool keep = false;
+        int count = 0;
+        if (s < nb && A.sk_id[s] != kDeadId) {
+            count = A.sk_id[19 * kSlots + s];
+            const float total = A.sk_sc[18 * kSlots + s];
+            keep = !(count < 2 || total / (float)count < 0.45f);
+        }
+        const unsigned long long mk = __ballot(keep);
+        if (keep) {
+            const int r = n_out + __popcll(mk & lanemask_lt());
+            if (r < PP_MAX_HUMANS) {
+                pp_human *hm = rec->humans + r;
+#pragma unroll 2
+                for (int kp = 0; kp < PP_NUM_PART; kp++) {
+                    const int id = A.sk_id[kp * kSlots + s];
+                    hm->peak_id[kp] = id;
+                    int x = 0, y = 0;
+                    float sc = 0.0f;
+                    if (id >= 0 && id < n_peaks) {  // getters index the flattened peak line BY ID (:299-309)
+                        int part = kp;
+                        if (id < A.off[kp] || id >= A.off[kp + 1]) {  // an id-sum of a merge: some other part's peak
+                            part = 0;
+                            while (id >= A.off[part + 1]) part++;
+                        }
+                        const float4 p = pk_g[(size_t)part * maxp + (id - A.off[part])];
+                        x = (int)p.x;
+                        y = (int)p.y;
+                        sc = p.z;
+                    }
+                    hm->x[kp] = x;
+                    hm->y[kp] = y;
+                    hm->part_score[kp] = sc;
+                }
+                hm->score = A.sk_sc[18 * kSlots + s] / (float)count;  // get_score, :295-297
+                hm->n_parts = count;
+            }
+        }
+        n_out += __popcll(mk);
+    }
+    const unsigned fl = or_flags(flags, img, 0, lane);
+    if (lane == 0) {
+        if (n_out > PP_MAX_HUMANS) {
+            st |= PP_ST_HUMAN_OVERFLOW;
+            n_out = PP_MAX_HUMANS;
+        }
+        rec->n_humans = n_out;
+        rec->n_peaks = n_peaks;
+        rec->n_connections = n_conn;
+        rec->status = fl | st;
+    }
+    stamp(stamps, img, 3);
+}
+
+__global__ __launch_bounds__(64, 3) void k_assemble_wave(int maxp, const float4 *__restrict__ peaks, const int *__restrict__ counts,
+                                                      const float4 *__restrict__ conns, const float4 *__restrict__ aux,
+                                                      const int *__restrict__ conn_counts, const unsigned *__restrict__ flags,
+                                                      pp_record *__restrict__ records) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int img = blockIdx.x;
+    assemble_image_wave(img, threadIdx.x, maxp, peaks + (size_t)img * PP_NUM_PART * maxp, counts + img * PP_NUM_PART,
+                        conns + (size_t)img * PP_NUM_LIMB * maxp, aux + (size_t)img * PP_NUM_LIMB * maxp,
+                        conn_counts + img * PP_NUM_LIMB, flags, records + img, lds_raw, d_stamps);
+}
+
+// K_B: LDS layout (dynamic): [map h*w T][cubic 16 f32][LimbLds: 40*maxp + 28*cap bytes]; the assembly tail re-uses the
+// whole region (assemble_wave_lds_bytes).
+// Grid (30, B): workgroup (limb, position) works on image order[position] -- K_A's last workgroup sorts the images by load,
+// heaviest first, so the crowded images' limbs are dispatched first and their assembly overlaps the rest of the batch.
+// "Last block done": every limb workgroup of an image publishes its connections (stores drained by every wave, workgroup
+// barrier, one agent-scope release, one relaxed agent-scope ticket on arrive[img]); the workgroup that draws the last of
+// the 30 tickets re-arms the counter for the next launch, acquires, and its wave 0 assembles the image while the other
+// waves leave.  No workgroup ever waits for another one, so dispatch order and residency cannot deadlock it.
 template <typename T>
-__global__ __launch_bounds__(kThreads) void k_limb_connect(const T *__restrict__ net, int n_samples, int h, int w,
+__global__ __launch_bounds__(kThreads, 3) void k_limb_connect(const T *__restrict__ net, int n_samples, int h, int w,
                                                            int flip, int maxp, int cap, int min_img_size,
                                                            const int *__restrict__ min_img_size_dev,
                                                            const float4 *__restrict__ peaks,
-                                                           const int *__restrict__ counts, float4 *__restrict__ conns,
-                                                           int *__restrict__ conn_counts, unsigned *__restrict__ status) {
+                                                           const int *__restrict__ counts, float4 *conns, float4 *aux,
+                                                           int *conn_counts, unsigned *status, const int *__restrict__ order,
+                                                           int *arrive, pp_record *records) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    const int limb = blockIdx.x, img = blockIdx.y;
+    __shared__ int s_poff[PP_NUM_PART];
+    __shared__ int s_last;
+    const int limb = blockIdx.x, img = order ? order[blockIdx.y] : blockIdx.y;
     const int pa = d_limb_pairs[limb][0], pb = d_limb_pairs[limb][1];
     int nA = counts[img * PP_NUM_PART + pa], nB = counts[img * PP_NUM_PART + pb];
     nA = nA < maxp ? nA : maxp;
     nB = nB < maxp ? nB : maxp;
     int *cc = conn_counts + img * PP_NUM_LIMB + limb;
+    long long *stamps = d_stamps;
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
     if (nA == 0 || nB == 0) {  // no candidate pairs: no connections (pafprocess.cpp:56-58, :111)
         if (threadIdx.x == 0) {
             *cc = 0;
             status[img * kFlagWords + PP_NUM_PART + limb] = 0u;
         }
-        return;
-    }
-    const int npix = h * w;
-    size_t off = 0;
-    T *smap = reinterpret_cast<T *>(lds_raw);
-    off += (sizeof(T) * (size_t)npix + 15) & ~(size_t)15;
-    float *s_cub = reinterpret_cast<float *>(lds_raw + off);
-    off += 64;
-    LimbLds L = carve_limb_lds(lds_raw + off, maxp, cap);
+    } else {
+        const int npix = h * w;
+        size_t off = 0;
+        T *smap = reinterpret_cast<T *>(lds_raw);
+        off += (sizeof(T) * (size_t)npix + 15) & ~(size_t)15;
+        float *s_cub = reinterpret_cast<float *>(lds_raw + off);
+        off += 64;
+        LimbLds L = carve_limb_lds(lds_raw + off, maxp, cap);
 
-    if (threadIdx.x < 16) s_cub[threadIdx.x] = d_cubic4[threadIdx.x >> 2][threadIdx.x & 3];
-    const float4 *pka = peaks + ((size_t)img * PP_NUM_PART + pa) * maxp;
-    const float4 *pkb = peaks + ((size_t)img * PP_NUM_PART + pb) * maxp;
-    for (int i = threadIdx.x; i < nA; i += kThreads) {
-        const float4 p = pka[i];
-        L.ax[i] = (int)p.x;  // Peak.x/y are ints: truncation (pafprocess.cpp:35-36)
-        L.ay[i] = (int)p.y;
-        L.as[i] = p.z;
+        if (threadIdx.x < 16) s_cub[threadIdx.x] = d_cubic4[threadIdx.x >> 2][threadIdx.x & 3];
+        if (threadIdx.x < 64) {  // flat peak id of each part's first peak (pafprocess.cpp:43-48)
+            int c = threadIdx.x < PP_NUM_PART ? counts[img * PP_NUM_PART + threadIdx.x] : 0;
+            c = c < maxp ? c : maxp;
+            int inc = c;
+#pragma unroll
+            for (int d = 1; d < 32; d <<= 1) {
+                const int t = __shfl_up(inc, d);
+                if ((int)threadIdx.x >= d) inc += t;
+            }
+            if (threadIdx.x < PP_NUM_PART) s_poff[threadIdx.x] = inc - c;
+        }
+        const float4 *pka = peaks + ((size_t)img * PP_NUM_PART + pa) * maxp;
+        const float4 *pkb = peaks + ((size_t)img * PP_NUM_PART + pb) * maxp;
+        for (int i = threadIdx.x; i < nA; i += kThreads) {
+            const float4 p = pka[i];
+            L.ax[i] = (int)p.x;  // Peak.x/y are ints: truncation (pafprocess.cpp:35-36)
+            L.ay[i] = (int)p.y;
+            L.as[i] = p.z;
+        }
+        for (int i = threadIdx.x; i < nB; i += kThreads) {
+            const float4 p = pkb[i];
+            L.bx[i] = (int)p.x;
+            L.by[i] = (int)p.y;
+            L.bs[i] = p.z;
+        }
+        const size_t plane = (size_t)npix;
+        const T *o0 = net + ((size_t)img * n_samples * PP_NUM_CH + limb) * plane;
+        const T *o1 = net + (((size_t)img * n_samples + 1) * PP_NUM_CH + d_flip_paf_ord[limb]) * plane;
+        stamp(stamps, wg, 0);
+        load_channel(smap, o0, o1, h, w, flip != 0);
+        __syncthreads();
+        stamp(stamps, wg, 1);
+
+        LdsBicubicSampler<T> smp{smap, s_cub, h, w};
+        const int mis = min_img_size_dev ? min_img_size_dev[img] : min_img_size;
+        const size_t row = ((size_t)img * PP_NUM_LIMB + limb) * maxp;
+        connect_limb(smp, L, nA, nB, cap, maxp, mis, conns + row, cc, status + img * kFlagWords + PP_NUM_PART + limb, stamps, wg,
+                     aux + row, s_poff[pa], s_poff[pb]);
     }
-    for (int i = threadIdx.x; i < nB; i += kThreads) {
-        const float4 p = pkb[i];
-        L.bx[i] = (int)p.x;
-        L.by[i] = (int)p.y;
-        L.bs[i] = p.z;
-    }
-    const size_t plane = (size_t)npix;
-    const T *o0 = net + ((size_t)img * n_samples * PP_NUM_CH + limb) * plane;
-    const T *o1 = net + (((size_t)img * n_samples + 1) * PP_NUM_CH + d_flip_paf_ord[limb]) * plane;
-    long long *stamps = d_stamps;
-    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
-    stamp(stamps, wg, 0);
-    load_channel(smap, o0, o1, h, w, flip != 0);
+    if (!arrive) return;  // two-kernel form (timing / diagnostics): k_assemble_wave follows as its own launch
+
+    // ---- publish this limb, draw a ticket
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // EVERY storing wave drains its stores
     __syncthreads();
-    stamp(stamps, wg, 1);
-
-    LdsBicubicSampler<T> smp{smap, s_cub, h, w};
-    const int mis = min_img_size_dev ? min_img_size_dev[img] : min_img_size;
-    connect_limb(smp, L, nA, nB, cap, maxp, mis, conns + ((size_t)img * PP_NUM_LIMB + limb) * maxp, cc,
-                 status + img * kFlagWords + PP_NUM_PART + limb, stamps, wg);
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ticket must not overtake the write-back
+        const int t = __hip_atomic_fetch_add(arrive + img, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = t == PP_NUM_LIMB - 1;
+        if (last) __hip_atomic_store(arrive + img, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last || threadIdx.x >= 64) return;
+    // ---- the image is complete: wave 0 of this workgroup assembles it (the LDS region is free: every wave passed the barrier)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop this CU's stale L1 lines; this wave is the only reader
+    __builtin_amdgcn_s_setprio(3);                       // a lone latency-bound instruction stream next to streaming waves
+    assemble_image_wave(img, threadIdx.x, maxp, peaks + (size_t)img * PP_NUM_PART * maxp, counts + img * PP_NUM_PART,
+                        conns + (size_t)img * PP_NUM_LIMB * maxp, aux + (size_t)img * PP_NUM_LIMB * maxp,
+                        conn_counts + img * PP_NUM_LIMB, status, records + img, lds_raw, nullptr);
 }
 
 // Drop-in path: the caller's (H, W, C) up-sampled map lives in global memory (uploaded by process_paf)
@@ -2463,7 +3063,9 @@ size_t lds_bytes_heat(int elem, int h, int w, int maxp) {
 }
 size_t lds_bytes_limb(int elem, int h, int w, int maxp, int cap) {
     const size_t npix = (size_t)h * w;
-    return ((elem * npix + 15) & ~(size_t)15) + 64 + limb_lds_bytes(maxp, cap);
+    const size_t limb = ((elem * npix + 15) & ~(size_t)15) + 64 + limb_lds_bytes(maxp, cap);
+    const size_t tail = assemble_wave_lds_bytes(maxp);  // the last limb workgroup of an image assembles it in the same region
+    return limb > tail ? limb : tail;
 }
 size_t lds_bytes_limb_hwc(int maxp, int cap) { return limb_lds_bytes(maxp, cap); }
 size_t lds_bytes_assemble(int maxp) { return assemble_lds_bytes(maxp); }
@@ -2482,6 +3084,7 @@ hipError_t init_kernel_attributes() {
                          reinterpret_cast<const void *>(&k_limb_connect<float>),
                          reinterpret_cast<const void *>(&k_limb_connect_hwc),
                          reinterpret_cast<const void *>(&k_assemble),
+                         reinterpret_cast<const void *>(&k_assemble_wave),
                          reinterpret_cast<const void *>(&k_limb_connect_py<__half>),
                          reinterpret_cast<const void *>(&k_limb_connect_py<float>),
                          reinterpret_cast<const void *>(&k_limb_connect_py_hwc),
@@ -2496,36 +3099,45 @@ hipError_t init_kernel_attributes() {
 }
 
 hipError_t launch_heat_peaks(const void *net, int dtype, int batch, int n_samples, int h, int w, int flip, int refine,
-                             int nms_mode, float thr, int maxp, float4 *peaks, int *counts, unsigned *status,
-                             hipStream_t stream) {
+                             int nms_mode, float thr, int maxp, float4 *peaks, int *counts, unsigned *status, int *order,
+                             int *arrive_all, hipStream_t stream) {
     const dim3 grid(PP_NUM_PART, batch), block(kThreads);
-    if (dtype == PP_F16) {
-        const size_t lds = lds_bytes_heat(2, h, w, maxp);
+    const size_t lds = lds_bytes_heat(dtype == PP_F16 ? 2 : 4, h, w, maxp);
+    if ((size_t)batch * sizeof(int) > lds) order = nullptr;  // the sorter keeps one int per image in the map's LDS region
+    if (dtype == PP_F16)
         hipLaunchKernelGGL(k_heat_peaks<__half>, grid, block, lds, stream, static_cast<const __half *>(net), n_samples, h,
-                           w, flip, refine, nms_mode, thr, maxp, peaks, counts, status);
-    } else {
-        const size_t lds = lds_bytes_heat(4, h, w, maxp);
+                           w, flip, refine, nms_mode, thr, maxp, peaks, counts, status, order, arrive_all);
+    else
         hipLaunchKernelGGL(k_heat_peaks<float>, grid, block, lds, stream, static_cast<const float *>(net), n_samples, h, w,
-                           flip, refine, nms_mode, thr, maxp, peaks, counts, status);
-    }
+                           flip, refine, nms_mode, thr, maxp, peaks, counts, status, order, arrive_all);
     return hipGetLastError();
+}
+bool heat_peaks_sorts(int dtype, int batch, int h, int w, int maxp) {
+    return (size_t)batch * sizeof(int) <= lds_bytes_heat(dtype == PP_F16 ? 2 : 4, h, w, maxp);
 }
 
 hipError_t launch_limb_connect(const void *net, int dtype, int batch, int n_samples, int h, int w, int flip, int maxp,
                                int cap, int min_img_size, const int *min_img_size_dev, const float4 *peaks,
-                               const int *counts, float4 *conns, int *conn_counts, unsigned *status,
-                               hipStream_t stream) {
+                               const int *counts, float4 *conns, float4 *aux, int *conn_counts, unsigned *status,
+                               const int *order, int *arrive, pp_record *records, hipStream_t stream) {
     const dim3 grid(PP_NUM_LIMB, batch), block(kThreads);
-    if (dtype == PP_F16) {
-        const size_t lds = lds_bytes_limb(2, h, w, maxp, cap);
+    const size_t lds = lds_bytes_limb(dtype == PP_F16 ? 2 : 4, h, w, maxp, cap);  // >= the assembly tail's need
+    if (dtype == PP_F16)
         hipLaunchKernelGGL(k_limb_connect<__half>, grid, block, lds, stream, static_cast<const __half *>(net), n_samples,
-                           h, w, flip, maxp, cap, min_img_size, min_img_size_dev, peaks, counts, conns, conn_counts,
-                           status);
-    } else {
-        const size_t lds = lds_bytes_limb(4, h, w, maxp, cap);
+                           h, w, flip, maxp, cap, min_img_size, min_img_size_dev, peaks, counts, conns, aux, conn_counts,
+                           status, order, arrive, records);
+    else
         hipLaunchKernelGGL(k_limb_connect<float>, grid, block, lds, stream, static_cast<const float *>(net), n_samples, h,
-                           w, flip, maxp, cap, min_img_size, min_img_size_dev, peaks, counts, conns, conn_counts, status);
-    }
+                           w, flip, maxp, cap, min_img_size, min_img_size_dev, peaks, counts, conns, aux, conn_counts, status,
+                           order, arrive, records);
+    return hipGetLastError();
+}
+
+hipError_t launch_assemble_wave(int batch, int maxp, const float4 *peaks, const int *counts, const float4 *conns,
+                                const float4 *aux, const int *conn_counts, const unsigned *status, pp_record *records,
+                                hipStream_t stream) {
+    hipLaunchKernelGGL(k_assemble_wave, dim3(batch), dim3(64), assemble_wave_lds_bytes(maxp), stream, maxp, peaks, counts, conns,
+                       aux, conn_counts, status, records);
     return hipGetLastError();
 }
 

@@ -114,7 +114,11 @@ class PosePostProcessor:
         stream = torch.cuda.current_stream(net_out.device).cuda_stream
         _lib.check(self.L.pp_time_kernels(self.ctx, B, C.c_void_p(net_out.data_ptr()), self._dtype_code(net_out), h, w,
                                           int(flip), int(min_img_size), int(iters), ms, C.c_void_p(stream)), self.ctx)
-        return {"k_heat_peaks": ms[0], "k_limb_connect": ms[1], "k_assemble": ms[2], "chain": ms[3]}
+        return {"k_heat_peaks": ms[0], "k_limb_connect": ms[1], "k_assemble_wave": ms[2], "chain": ms[3]}
+
+    def set_mode(self, mode: int):
+        """pp_debug_set_mode: 0 fused + load-ordered (default), 1 separate assembly launch, 2 fused without ordering"""
+        _lib.check(self.L.pp_debug_set_mode(self.ctx, int(mode)), self.ctx)
 
     def read_peaks(self, image: int) -> np.ndarray:
         cap = _lib.NUM_PART * self.maxp

@@ -131,8 +131,10 @@ PP_API int pp_nms_batch_ex(pp_ctx *ctx, int batch, const void *net_out_dev, int 
 
 /* Measurement aid: runs the kernels of pp_process_batch `iters` times EACH on `stream`, bracketed by HIP
  * events on that stream, and returns the average duration of one launch in milliseconds:
- * ms_out[0] = k_heat_peaks, ms_out[1] = k_limb_connect, ms_out[2] = k_assemble, ms_out[3] = the whole chain as
- * pp_process_batch enqueues it (all launches back to back).  ms_out must hold 4 floats.  Blocking. */
+ * ms_out[0] = k_heat_peaks (peaks + the image ordering), ms_out[1] = k_limb_connect (limb scoring, matching AND the
+ * person assembly done by each image's last limb workgroup), ms_out[2] = k_assemble_wave (the assembly alone as its own
+ * one-wave-per-image launch; diagnostic, not part of the chain), ms_out[3] = the whole chain as pp_process_batch enqueues it.
+ * ms_out must hold 4 floats.  Blocking. */
 PP_API int pp_time_kernels(pp_ctx *ctx, int batch, const void *net_out_dev, int dtype, int h, int w, int flip,
                            int min_img_size, int iters, float *ms_out, void *stream);
 
@@ -195,6 +197,10 @@ PP_API int pp_flip_average(const void *net_out_dev, int dtype, int batch, int h,
 /* Diagnostics: register a DEVICE buffer of 8 int64 per workgroup; K_A and K_B then store shader-clock stamps at
  * their phase boundaries (slot 0 start, 1 map in LDS, ...).  NULL (default) disables it. */
 PP_API int pp_debug_set_stamps(long long *stamps_dev);
+/* Diagnostics / A-B measurements of pp_process_batch's launch structure: 0 (default) two launches -- peaks, then limb matching
+ * with the person assembly done by each image's last limb workgroup, images dispatched heaviest first; 1 = limb matching and
+ * assembly as separate launches; 2 = as 0 without the load ordering.  Results are identical in every mode. */
+PP_API int pp_debug_set_mode(pp_ctx *ctx, int mode);
 
 /* Blocking read-backs of the context's workspace for the last batch (host pointers).
  * pp_read_peaks: joint_list rows [x, y, score, peak_id, part] (evaluate.py:99-103) of one image; returns
