@@ -81,6 +81,20 @@ __device__ __forceinline__ unsigned long long lanemask_lt() {
     return (1ull << (threadIdx.x & 63)) - 1ull;
 }
 
+// Write-through (sc1) stores for data that ANOTHER workgroup of the same launch reads (K_B's connections, read by the
+// workgroup that assembles the image): the bytes leave the XCD's L2 with the store, so the publisher needs no agent-scope
+// release fence -- every storing wave drains its stores (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, one lane
+// draws the ticket; the reader acquires (cdna_hip_programming.md Guideline 16, form R1).
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_sc1(float4 *p, const float4 &v) {
+    const f32x4_t q = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(q) : "memory");
+}
+__device__ __forceinline__ void store_sc1(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void store_sc1(unsigned *p, unsigned v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Per-image status flags: one word per producing workgroup -- [0, 18) written by the peak kernel of each part, [18, 48) by
 // the limb kernel of each limb -- stored with a PLAIN store by every workgroup on every launch (early exits included), and
 // OR-ed by the assembly.  Nothing is ever zeroed by a memset and nothing is accumulated with atomics, so no word can
@@ -1115,16 +1129,16 @@ __device__ void connect_limb(const Sampler &smp, const LimbLds &L, int nA, int n
             const unsigned idx = L.c_idx[t];
             const int ia = (int)(idx & 0xffffu), ib = (int)(idx >> 16);
             const int o = ncn + before + __popcll(m & lanemask_lt());
-            conn_out[o] = make_float4(__int_as_float(ia), __int_as_float(ib), L.c_score[t], L.c_len[t]);
+            store_sc1(conn_out + o, make_float4(__int_as_float(ia), __int_as_float(ib), L.c_score[t], L.c_len[t]));
             // what the assembly needs besides: the two peaks' ids (position in the part-ordered peak line,
             // pafprocess.cpp:34, :43-48) and their scores (pl[id].score, :162, :266)
-            if (aux_out) aux_out[o] = make_float4(__int_as_float(offA + ia), __int_as_float(offB + ib), L.as[ia], L.bs[ib]);
+            if (aux_out) store_sc1(aux_out + o, make_float4(__int_as_float(offA + ia), __int_as_float(offB + ib), L.as[ia], L.bs[ib]));
         }
         ncn += all;
     }
     if (threadIdx.x == 0) {
-        *conn_count = ncn;
-        *status_word = st;  // plain store, every launch (no memset / atomic protocol)
+        store_sc1(conn_count, ncn);
+        store_sc1(status_word, st);  // a store on every launch (no memset / atomic-OR protocol)
     }
     stamp(stamps, wg, 5);
 }
@@ -1164,7 +1178,7 @@ struct AsmWaveLds {
     int *sk_id;    // [20][kSlots] rows 0..17 peak id per part (-1 empty, kDeadId erased), row 19 part count
     float *sk_sc;  // [20][kSlots] rows 0..17 limb score per part, row 18 total score, row 19 longest limb
     int *cb1, *cb2;  // [maxp] tag | connection lane, by end-point rank within the part
-    int *cnt, *conf;  // [64]
+    int *cnt;        // [64] matching skeletons per connection lane (+ 256 per shared skeleton)
     int *off;        // [19] flat peak id of the first peak of each part (+ total)
 };
 __device__ inline AsmWaveLds carve_asm_wave_lds(unsigned char *p, int maxp) {
@@ -1174,8 +1188,7 @@ __device__ inline AsmWaveLds carve_asm_wave_lds(unsigned char *p, int maxp) {
     A.cb1 = reinterpret_cast<int *>(A.sk_sc + 20 * kSlots);
     A.cb2 = A.cb1 + maxp;
     A.cnt = A.cb2 + maxp;
-    A.conf = A.cnt + 64;
-    A.off = A.conf + 64;
+    A.off = A.cnt + 64;
     return A;
 }
 
@@ -1232,12 +1245,274 @@ __device__ __forceinline__ void load_cache(SkelCache &k, const AsmWaveLds &A, in
     k.tt = valid ? A.sk_sc[18 * kSlots + slot] : 0.0f;
 }
 
+// State of one image's assembly that outlives a pass (all wave-uniform).
+struct AsmState {
+    int nb;        // slots used so far
+    unsigned st;   // PP_ST_* raised by the assembly itself
+    long long seq_conns, seq_cycles, odd_merges, class_cycles;  // diagnostics (stamps only)
+};
+
+// One pass: <= 64 connections of one limb against the skeletons in slots [0, S.nb), NB = number of 64-slot banks those
+// slots span (compile time: the per-bank register caches and every per-bank step are unrolled NB times, so the common
+// case -- fewer than 64 skeletons so far -- runs a quarter of the instructions of the general one).
+template <int NB>
+__device__ __forceinline__ void assemble_pass(AsmState &S, const AsmWaveLds &A, int lane, int mc, int tag, int part1, int part2,
+                                              int off1, int off2, int cnt1, int cnt2, int id1, int id2, float c_score,
+                                              float c_len, float ps1, float ps2, long long *stamps) {
+    const bool have = lane < mc;
+    const long long tc0 = stamps ? (long long)clock64() : 0;
+    // ---- 1. cache the words of every skeleton this limb can touch; publish "end point -> connection lane"
+    SkelCache K[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) load_cache(K[b], A, b * 64 + lane, part1, part2, b * 64 + lane < S.nb);
+    if (have) {
+        A.cb1[id1 - off1] = tag | lane;  // end points are pairwise different within a limb: no write conflicts
+        A.cb2[id2 - off2] = tag | lane;
+    }
+    A.cnt[lane] = 0;
+    wave_lds_sync();
+    // ---- 2. classification: cnt[c] = number of skeletons matching connection c (:143-150), + 256 when c shares one
+    int myk[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        const int r1 = K[b].p1 - off1, r2 = K[b].p2 - off2;  // erased / unused slots: negative
+        int k1 = -1, k2 = -1;
+        if (r1 >= 0 && r1 < cnt1) {
+            const int v = A.cb1[r1];
+            if ((v & ~0xff) == tag) k1 = v & 0xff;
+        }
+        if (r2 >= 0 && r2 < cnt2) {
+            const int v = A.cb2[r2];
+            if ((v & ~0xff) == tag) k2 = v & 0xff;
+        }
+        const bool two = k1 >= 0 && k2 >= 0 && k1 != k2;  // one skeleton, two connections: their order matters
+        if (k1 >= 0) atomicAdd(&A.cnt[k1], two ? 257 : 1);  // one count per matching SKELETON
+        if (k2 >= 0 && k2 != k1) atomicAdd(&A.cnt[k2], two ? 257 : 1);
+        myk[b] = two ? -1 : (k1 >= 0 ? k1 : k2);
+    }
+    wave_lds_sync();
+    const int cw = have ? A.cnt[lane] : 0;
+    const bool conflict = cw >= 2;  // two or more skeletons (possible merge / no action), or a shared skeleton
+    const bool isnew = have && cw == 0;
+    unsigned long long confm = __ballot(conflict);
+    // connection words for the skeleton lanes that apply a found-1 update in a run
+    int f_id2[NB];
+    float f_cs[NB], f_cl[NB], f_ps2[NB];
+    bool any_par = false;
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        if (myk[b] >= 0 && ((confm >> myk[b]) & 1ull)) myk[b] = -1;  // its connection goes one by one
+        any_par |= myk[b] >= 0;
+    }
+    if (__ballot(any_par)) {
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const int src = myk[b] >= 0 ? myk[b] : lane;
+            f_id2[b] = __shfl(id2, src);
+            f_cs[b] = __shfl(c_score, src);
+            f_cl[b] = __shfl(c_len, src);
+            f_ps2[b] = __shfl(ps2, src);
+        }
+    }
+    if (stamps) S.class_cycles += (long long)clock64() - tc0;
+    // ---- 3. in connection order: maximal runs of independent connections in one step, the others one by one
+    int pos = 0;
+    while (pos < mc) {
+        const unsigned long long rest = confm >> pos;
+        int next = rest ? pos + __ffsll((long long)rest) - 1 : mc;
+        next = next < mc ? next : mc;
+        if (next > pos) {
+#pragma unroll
+            for (int b = 0; b < NB; b++)
+                if (myk[b] >= pos && myk[b] < next) apply_found1(K[b], A, b * 64 + lane, part2, f_id2[b], f_cs[b], f_cl[b], f_ps2[b]);
+            const bool born = isnew && lane >= pos && lane < next;
+            const unsigned long long mnew = __ballot(born);
+            if (mnew) {  // :257-273 new skeletons, slots in connection order
+                const int slot = S.nb + __popcll(mnew & lanemask_lt());
+                if (born && slot < kSlots) {
+                    A.sk_id[part1 * kSlots + slot] = id1;
+                    A.sk_sc[part1 * kSlots + slot] = c_score;
+                    A.sk_id[part2 * kSlots + slot] = id2;
+                    A.sk_sc[part2 * kSlots + slot] = c_score;
+                    A.sk_id[19 * kSlots + slot] = 2;
+                    A.sk_sc[19 * kSlots + slot] = c_len;
+                    A.sk_sc[18 * kSlots + slot] = __fadd_rn(__fadd_rn(ps1, ps2), c_score);
+                }
+                S.nb += __popcll(mnew);
+                if (S.nb > kSlots) {
+                    S.nb = kSlots;
+                    S.st |= PP_ST_SKEL_OVERFLOW;
+                }
+            }
+        }
+        if (next < mc) {  // ---- the reference's scan for connection `next`, on the cached registers
+            const long long t0 = stamps ? (long long)clock64() : 0;
+            const int u_id1 = rl(id1, next), u_id2 = rl(id2, next);
+            const float u_cs = rlf(c_score, next), u_cl = rlf(c_len, next);
+            int num_found = 0, idx1 = 0, idx2 = 0;
+#pragma unroll
+            for (int b = 0; b < NB; b++) {  // slots born during this pass cannot match (pairwise different end points)
+                const unsigned long long mk = __ballot(K[b].p1 == u_id1 || K[b].p2 == u_id2);
+                if (mk) {
+                    if (num_found == 0) {
+                        idx1 = b * 64 + __ffsll((long long)mk) - 1;
+                        const unsigned long long m2 = mk & (mk - 1);
+                        if (m2) idx2 = b * 64 + __ffsll((long long)m2) - 1;
+                    } else if (num_found == 1) {
+                        idx2 = b * 64 + __ffsll((long long)mk) - 1;
+                    }
+                    num_found += __popcll(mk);
+                }
+            }
+            if (num_found == 1) {
+                const float u_ps2 = rlf(ps2, next);
+#pragma unroll
+                for (int b = 0; b < NB; b++)
+                    if ((idx1 >> 6) == b && (idx1 & 63) == lane) apply_found1(K[b], A, idx1, part2, u_id2, u_cs, u_cl, u_ps2);
+            } else if (num_found == 2) {  // :182-256, one part per lane; LDS is current (write-through)
+                wave_lds_sync();
+                const bool isp = lane < PP_NUM_PART;
+                const int a_i1 = isp ? A.sk_id[lane * kSlots + idx1] : -1, a_i2 = isp ? A.sk_id[lane * kSlots + idx2] : -1;
+                const float a_f1 = isp ? A.sk_sc[lane * kSlots + idx1] : 0.0f, a_f2 = isp ? A.sk_sc[lane * kSlots + idx2] : 0.0f;
+                const bool a1 = a_i1 > 0, a2 = a_i2 > 0;  // :200-201 id 0 counts as unassigned
+                if (__ballot(a1 && a2) == 0) {
+                    // :203-214 running minima "min = (min == 0) ? v : min(v, min)": a plain minimum unless a value is exactly 0
+                    float min1, min2;
+                    if (__ballot((a1 && a_f1 == 0.0f) || (a2 && a_f2 == 0.0f))) {
+                        min1 = 0.0f;
+                        min2 = 0.0f;
+#pragma unroll 1
+                        for (int kp = 0; kp < PP_NUM_PART; kp++) {
+                            const int i1 = rl(a_i1, kp), i2 = rl(a_i2, kp);
+                            const float f1 = rlf(a_f1, kp), f2 = rlf(a_f2, kp);
+                            if (i1 > 0) min1 = (min1 == 0.0f) ? f1 : (f1 < min1 ? f1 : min1);
+                            if (i2 > 0) min2 = (min2 == 0.0f) ? f2 : (f2 < min2 ? f2 : min2);
+                        }
+                    } else {
+                        const float inf = __int_as_float(0x7f800000);
+                        min1 = a1 ? a_f1 : inf;
+                        min2 = a2 ? a_f2 : inf;
+#pragma unroll
+                        for (int d = 16; d >= 1; d >>= 1) {
+                            min1 = fminf(min1, __shfl_xor(min1, d));
+                            min2 = fminf(min2, __shfl_xor(min2, d));
+                        }
+                        min1 = rlf(min1, 0);
+                        min2 = rlf(min2, 0);
+                        if (min1 == inf) min1 = 0.0f;
+                        if (min2 == inf) min2 = 0.0f;
+                    }
+                    const float len1 = A.sk_sc[19 * kSlots + idx1];
+                    const int min_len = (int)__fmul_rn(len1, 16.0f);
+                    const float lim = __fmul_rn((min2 < min1 ? min2 : min1), 0.7f);  // :220
+                    if (u_cs >= lim || u_cl < (float)min_len) {                       // :221 OR
+                        // a limb column where BOTH rows hold an id gets their sum + 1: an id this pass's tables never saw
+                        const bool odd = __ballot((lane == part1 || lane == part2) && a_i1 >= 0 && a_i2 >= 0) != 0;
+                        const float tot = __fadd_rn(A.sk_sc[18 * kSlots + idx1], __fadd_rn(A.sk_sc[18 * kSlots + idx2], u_cs));
+                        const int cnt = A.sk_id[19 * kSlots + idx1] + A.sk_id[19 * kSlots + idx2];
+                        wave_lds_sync();
+                        if (isp) {
+                            A.sk_id[lane * kSlots + idx1] = a_i1 + (a_i2 + 1);
+                            A.sk_sc[lane * kSlots + idx1] = __fadd_rn(a_f1, __fadd_rn(a_f2, 1.0f));
+                            A.sk_id[lane * kSlots + idx2] = kDeadId;  // skeletons.erase(begin + idx2), :228
+                        }
+                        if (lane == 0) {
+                            A.sk_id[19 * kSlots + idx1] = cnt;
+                            A.sk_sc[19 * kSlots + idx1] = len1 < u_cl ? u_cl : len1;
+                            A.sk_sc[18 * kSlots + idx1] = tot;
+                        }
+                        wave_lds_sync();
+#pragma unroll
+                        for (int b = 0; b < NB; b++) {  // refresh the two owners' caches
+                            if ((idx1 >> 6) == b && (idx1 & 63) == lane) load_cache(K[b], A, idx1, part1, part2, true);
+                            if ((idx2 >> 6) == b && (idx2 & 63) == lane) K[b].p1 = K[b].p2 = kDeadId;
+                        }
+                        if (odd) {  // from here on every connection of this pass scans, as the reference does
+                            confm |= next + 1 < 64 ? ~0ull << (next + 1) : 0ull;
+#pragma unroll
+                            for (int b = 0; b < NB; b++) myk[b] = -1;
+                            S.odd_merges++;
+                        }
+                    }
+                }
+            } else if (num_found == 0) {  // :257-273
+                if (S.nb < kSlots) {
+                    if (lane == 0) {
+                        const float u_ps1 = rlf(ps1, next), u_ps2 = rlf(ps2, next);
+                        A.sk_id[part1 * kSlots + S.nb] = u_id1;
+                        A.sk_sc[part1 * kSlots + S.nb] = u_cs;
+                        A.sk_id[part2 * kSlots + S.nb] = u_id2;
+                        A.sk_sc[part2 * kSlots + S.nb] = u_cs;
+                        A.sk_id[19 * kSlots + S.nb] = 2;
+                        A.sk_sc[19 * kSlots + S.nb] = u_cl;
+                        A.sk_sc[18 * kSlots + S.nb] = __fadd_rn(__fadd_rn(u_ps1, u_ps2), u_cs);
+                    }
+                    S.nb++;
+                } else {
+                    S.st |= PP_ST_SKEL_OVERFLOW;
+                }
+            }
+            // num_found > 2: no action
+            if (stamps) {
+                S.seq_cycles += (long long)clock64() - t0;
+                S.seq_conns++;
+            }
+        }
+        pos = next + 1;
+    }
+}
+
+// out of slots: drop the erased ones, order preserved (rare: more than 256 births in one image)
+__device__ __forceinline__ void assemble_compact(const AsmWaveLds &A, int lane, int &nb) {
+    bool alive[kBanks];
+    int newpos[kBanks];
+    int base = 0;
+#pragma unroll
+    for (int b = 0; b < kBanks; b++) {
+        const int slot = b * 64 + lane;
+        alive[b] = slot < nb && A.sk_id[slot] != kDeadId;
+        const unsigned long long mk = __ballot(alive[b]);
+        newpos[b] = base + __popcll(mk & lanemask_lt());
+        base += __popcll(mk);
+    }
+#pragma unroll 1
+    for (int row = 0; row < 20; row++) {
+        int vi[kBanks];
+        float vf[kBanks];
+#pragma unroll
+        for (int b = 0; b < kBanks; b++) {
+            vi[b] = A.sk_id[row * kSlots + b * 64 + lane];
+            vf[b] = A.sk_sc[row * kSlots + b * 64 + lane];
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int b = 0; b < kBanks; b++)
+            if (alive[b]) {
+                A.sk_id[row * kSlots + newpos[b]] = vi[b];
+                A.sk_sc[row * kSlots + newpos[b]] = vf[b];
+            }
+        wave_lds_sync();
+        if (row < 18)
+#pragma unroll
+            for (int b = 0; b < kBanks; b++) {
+                const int slot = b * 64 + lane;
+                if (slot >= base && slot < nb) {
+                    A.sk_id[row * kSlots + slot] = -1;
+                    A.sk_sc[row * kSlots + slot] = -1.0f;
+                }
+            }
+    }
+    wave_lds_sync();
+    nb = base;
+}
+
 // Executed by all 64 lanes of ONE wave (lane = threadIdx.x & 63); `lds` holds assemble_wave_lds_bytes(maxp) bytes that no
 // other wave touches.  conns / aux: [30][maxp] of this image; cc_g: its 30 connection counts; cnt_g: its 18 peak counts.
-__device__ __forceinline__ void assemble_image_wave(int img, int lane, int maxp, const float4 *__restrict__ pk_g, const int *__restrict__ cnt_g,
-                                    const float4 *__restrict__ conns, const float4 *__restrict__ aux,
-                                    const int *__restrict__ cc_g, const unsigned *__restrict__ flags,
-                                    pp_record *__restrict__ rec, unsigned char *lds, long long *stamps) {
+__device__ __forceinline__ void assemble_image_wave(int img, int lane, int maxp, const float4 *__restrict__ pk_g,
+                                                    const int *__restrict__ cnt_g, const float4 *__restrict__ conns,
+                                                    const float4 *__restrict__ aux, const int *__restrict__ cc_g,
+                                                    const unsigned *__restrict__ flags, pp_record *__restrict__ rec,
+                                                    unsigned char *lds, long long *stamps) {
     const AsmWaveLds A = carve_asm_wave_lds(lds, maxp);
     stamp(stamps, img, 0);
     // ---- counts -> flat id offsets (pafprocess.cpp:43-48 flattens in part order); per-limb connection counts
@@ -1255,6 +1530,9 @@ __device__ __forceinline__ void assemble_image_wave(int img, int lane, int maxp,
         }
     }
     const int offv = inc - pc;  // lane p: flat id of part p's first peak
+    // the limb table in a register (lane l: the two parts of limb l): a per-limb memory load would also wait for the
+    // prefetched connections (s_waitcnt vmcnt counts every vector memory operation of the wave)
+    const int lpv = lane < PP_NUM_LIMB ? ((int)d_limb_pairs[lane][0] | ((int)d_limb_pairs[lane][1] << 8)) : 0;
     const int n_peaks = rl(inc, PP_NUM_PART - 1);
     const int n_conn = rl(cinc, PP_NUM_LIMB - 1);
     if (lane <= PP_NUM_PART) A.off[lane] = lane < PP_NUM_PART ? offv : n_peaks;
@@ -1279,13 +1557,14 @@ __device__ __forceinline__ void assemble_image_wave(int img, int lane, int maxp,
     wave_lds_sync();
     stamp(stamps, img, 1);
 
-    int nb = 0;  // slots used so far (uniform)
-    unsigned st = 0;
-    long long seq_conns = 0, seq_cycles = 0, odd_merges = 0;
-    SkelCache K[kBanks];
+    AsmState S{0, 0u, 0, 0, 0, 0};
     for (int limb = 0; limb < PP_NUM_LIMB; limb++) {
         const int m = rl(cc, limb);
+        // this limb's connections were requested one limb ago: wait for them HERE, before the next request goes out, so that
+        // no later wait of this iteration has to cover the new request as well (vmcnt retires in order)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         float4 cur_cn = pre_cn, cur_ax = pre_ax;
+        asm volatile("" : "+v"(cur_cn.z), "+v"(cur_cn.w), "+v"(cur_ax.x), "+v"(cur_ax.y), "+v"(cur_ax.z), "+v"(cur_ax.w));
         if (limb + 1 < PP_NUM_LIMB) {  // next limb's first 64 connections: in flight during this limb
             const int mn = rl(cc, limb + 1);
             if (lane < mn) {
@@ -1294,334 +1573,105 @@ __device__ __forceinline__ void assemble_image_wave(int img, int lane, int maxp,
             }
         }
         if (m == 0) continue;
-        const int part1 = d_limb_pairs[limb][0], part2 = d_limb_pairs[limb][1];
+        const int lp2 = rl(lpv, limb);
+        const int part1 = lp2 & 0xff, part2 = lp2 >> 8;
         const int off1 = rl(offv, part1), off2 = rl(offv, part2);
         const int cnt1 = rl(pc, part1), cnt2 = rl(pc, part2);
-        for (int c0 = 0; c0 < m; c0 += 64) {  // passes of <= 64 connections (a second pass only with max_peaks_per_part > 64)
-            const int mc = m - c0 < 64 ? m - c0 : 64;
-            if (c0 > 0 && lane < mc) {
-                cur_cn = conns[(size_t)limb * maxp + c0 + lane];
-                cur_ax = aux[(size_t)limb * maxp + c0 + lane];
-            }
-            const bool have = lane < mc;
+        {  // first pass: the prefetched connections (the only pass unless max_peaks_per_part > 64)
+            const int mc = m < 64 ? m : 64;
+            if (S.nb + mc > kSlots) assemble_compact(A, lane, S.nb);
             const int id1 = __float_as_int(cur_ax.x), id2 = __float_as_int(cur_ax.y);
-            const float c_score = cur_cn.z, c_len = cur_cn.w, ps1 = cur_ax.z, ps2 = cur_ax.w;
-
-            if (nb + mc > kSlots) {  // ---- out of slots: drop the erased ones, order preserved (rare)
-                bool alive[kBanks];
-                int newpos[kBanks];
-                int base = 0;
-#pragma unroll
-                for (int b = 0; b < kBanks; b++) {
-                    const int slot = b * 64 + lane;
-                    alive[b] = slot < nb && A.sk_id[slot] != kDeadId;
-                    const unsigned long long mk = __ballot(alive[b]);
-                    newpos[b] = base + __popcll(mk & lanemask_lt());
-                    base += __popcll(mk);
-                }
-#pragma unroll 1
-                for (int row = 0; row < 20; row++) {
-                    int vi[kBanks];
-                    float vf[kBanks];
-#pragma unroll
-                    for (int b = 0; b < kBanks; b++) {
-                        vi[b] = A.sk_id[row * kSlots + b * 64 + lane];
-                        vf[b] = A.sk_sc[row * kSlots + b * 64 + lane];
-                    }
-                    wave_lds_sync();
-#pragma unroll
-                    for (int b = 0; b < kBanks; b++)
-                        if (alive[b]) {
-                            A.sk_id[row * kSlots + newpos[b]] = vi[b];
-                            A.sk_sc[row * kSlots + newpos[b]] = vf[b];
-                        }
-                    wave_lds_sync();
-                    if (row < 18)
-#pragma unroll
-                        for (int b = 0; b < kBanks; b++) {
-                            const int slot = b * 64 + lane;
-                            if (slot >= base && slot < nb) {
-                                A.sk_id[row * kSlots + slot] = -1;
-                                A.sk_sc[row * kSlots + slot] = -1.0f;
-                            }
-                        }
-                }
-                wave_lds_sync();
-                nb = base;
+            const int tag = (2 * limb + 1) << 8;  // unique per pass; the tables never need re-zeroing
+            if (S.nb <= 64)
+                assemble_pass<1>(S, A, lane, mc, tag, part1, part2, off1, off2, cnt1, cnt2, id1, id2, cur_cn.z, cur_cn.w, cur_ax.z,
+                                 cur_ax.w, stamps);
+            else if (S.nb <= 128)
+                assemble_pass<2>(S, A, lane, mc, tag, part1, part2, off1, off2, cnt1, cnt2, id1, id2, cur_cn.z, cur_cn.w, cur_ax.z,
+                                 cur_ax.w, stamps);
+            else
+                assemble_pass<kBanks>(S, A, lane, mc, tag, part1, part2, off1, off2, cnt1, cnt2, id1, id2, cur_cn.z, cur_cn.w,
+                                      cur_ax.z, cur_ax.w, stamps);
+        }
+        if (m > 64) {  // connections 64.. of a limb (its own loads and its own copy of the pass: a load here would otherwise make
+                       // every wait of the common path cover the prefetch as well)
+            const int mc = m - 64;
+            float4 cn2 = make_float4(0.f, 0.f, 0.f, 0.f), ax2 = cn2;
+            if (lane < mc) {
+                cn2 = conns[(size_t)limb * maxp + 64 + lane];
+                ax2 = aux[(size_t)limb * maxp + 64 + lane];
             }
-
-            // ---- 1. cache the words of every skeleton this limb can touch
-#pragma unroll
-            for (int b = 0; b < kBanks; b++)
-                if (b * 64 < nb) load_cache(K[b], A, b * 64 + lane, part1, part2, b * 64 + lane < nb);
-                else K[b].p1 = K[b].p2 = kDeadId;
-            // ---- 2. classification
-            const int tag = (2 * limb + (c0 ? 1 : 0) + 1) << 8;  // unique per pass; the tables never need re-zeroing
-            if (have) {
-                A.cb1[id1 - off1] = tag | lane;  // end points are pairwise different within a limb: no write conflicts
-                A.cb2[id2 - off2] = tag | lane;
-            }
-            A.cnt[lane] = 0;
-            A.conf[lane] = 0;
-            wave_lds_sync();
-            int myk[kBanks];
-#pragma unroll
-            for (int b = 0; b < kBanks; b++) {
-                myk[b] = -1;
-                if (b * 64 < nb) {
-                    const int r1 = K[b].p1 - off1, r2 = K[b].p2 - off2;  // erased / unused slots: negative
-                    int k1 = -1, k2 = -1;
-                    if (r1 >= 0 && r1 < cnt1) {
-                        const int v = A.cb1[r1];
-                        if ((v & ~0xff) == tag) k1 = v & 0xff;
-                    }
-                    if (r2 >= 0 && r2 < cnt2) {
-                        const int v = A.cb2[r2];
-                        if ((v & ~0xff) == tag) k2 = v & 0xff;
-                    }
-                    if (k1 >= 0) atomicAdd(&A.cnt[k1], 1);  // one count per matching SKELETON (:146-149)
-                    if (k2 >= 0 && k2 != k1) atomicAdd(&A.cnt[k2], 1);
-                    if (k1 >= 0 && k2 >= 0 && k1 != k2) {  // one skeleton, two connections: order matters
-                        A.conf[k1] = 1;
-                        A.conf[k2] = 1;
-                    } else {
-                        myk[b] = k1 >= 0 ? k1 : k2;
-                    }
-                }
-            }
-            wave_lds_sync();
-            const int nfound = have ? A.cnt[lane] : 0;
-            const bool conflict = have && (A.conf[lane] != 0 || nfound >= 2);
-            const bool isnew = have && nfound == 0;
-            unsigned long long confm = __ballot(conflict);
-            bool any_par = false;
-#pragma unroll
-            for (int b = 0; b < kBanks; b++) {
-                if (myk[b] >= 0 && ((confm >> myk[b]) & 1ull)) myk[b] = -1;  // its connection goes one by one
-                any_par |= myk[b] >= 0;
-            }
-            // connection words for the skeleton lanes that apply a found-1 update in a run
-            int f_id2[kBanks];
-            float f_cs[kBanks], f_cl[kBanks], f_ps2[kBanks];
-            if (__ballot(any_par)) {
-#pragma unroll
-                for (int b = 0; b < kBanks; b++) {
-                    const int src = myk[b] >= 0 ? myk[b] : lane;
-                    f_id2[b] = __shfl(id2, src);
-                    f_cs[b] = __shfl(c_score, src);
-                    f_cl[b] = __shfl(c_len, src);
-                    f_ps2[b] = __shfl(ps2, src);
-                }
-            }
-            // ---- 3. in connection order: maximal runs of independent connections in one step, the others one by one
-            int pos = 0;
-            while (pos < mc) {
-                const unsigned long long rest = confm >> pos;
-                int next = rest ? pos + __ffsll((long long)rest) - 1 : mc;
-                next = next < mc ? next : mc;
-                if (next > pos) {
-#pragma unroll
-                    for (int b = 0; b < kBanks; b++)
-                        if (myk[b] >= pos && myk[b] < next)
-                            apply_found1(K[b], A, b * 64 + lane, part2, f_id2[b], f_cs[b], f_cl[b], f_ps2[b]);
-                    const bool born = isnew && lane >= pos && lane < next;
-                    const unsigned long long mnew = __ballot(born);
-                    if (mnew) {  // :257-273 new skeletons, slots in connection order
-                        const int slot = nb + __popcll(mnew & lanemask_lt());
-                        if (born && slot < kSlots) {
-                            A.sk_id[part1 * kSlots + slot] = id1;
-                            A.sk_sc[part1 * kSlots + slot] = c_score;
-                            A.sk_id[part2 * kSlots + slot] = id2;
-                            A.sk_sc[part2 * kSlots + slot] = c_score;
-                            A.sk_id[19 * kSlots + slot] = 2;
-                            A.sk_sc[19 * kSlots + slot] = c_len;
-                            A.sk_sc[18 * kSlots + slot] = __fadd_rn(__fadd_rn(ps1, ps2), c_score);
-                        }
-                        nb += __popcll(mnew);
-                        if (nb > kSlots) {
-                            nb = kSlots;
-                            st |= PP_ST_SKEL_OVERFLOW;
-                        }
-                    }
-                }
-                if (next < mc) {  // ---- the reference's scan for connection `next`, on the cached registers
-                    const long long t0 = stamps ? (long long)clock64() : 0;
-                    const int u_id1 = rl(id1, next), u_id2 = rl(id2, next);
-                    const float u_cs = rlf(c_score, next), u_cl = rlf(c_len, next);
-                    const float u_ps1 = rlf(ps1, next), u_ps2 = rlf(ps2, next);
-                    int num_found = 0, idx1 = 0, idx2 = 0;
-#pragma unroll
-                    for (int b = 0; b < kBanks; b++) {
-                        if (b * 64 < nb) {
-                            unsigned long long mk = __ballot(K[b].p1 == u_id1 || K[b].p2 == u_id2);
-                            if (mk) {
-                                if (num_found == 0) {
-                                    idx1 = b * 64 + __ffsll((long long)mk) - 1;
-                                    const unsigned long long m2 = mk & (mk - 1);
-                                    if (m2) idx2 = b * 64 + __ffsll((long long)m2) - 1;
-                                } else if (num_found == 1) {
-                                    idx2 = b * 64 + __ffsll((long long)mk) - 1;
-                                }
-                                num_found += __popcll(mk);
-                            }
-                        }
-                    }
-                    if (num_found == 1) {
-#pragma unroll
-                        for (int b = 0; b < kBanks; b++)
-                            if ((idx1 >> 6) == b && (idx1 & 63) == lane) apply_found1(K[b], A, idx1, part2, u_id2, u_cs, u_cl, u_ps2);
-                    } else if (num_found == 2) {  // :182-256, one part per lane; LDS is current (write-through)
-                        wave_lds_sync();
-                        const bool isp = lane < PP_NUM_PART;
-                        const int a_i1 = isp ? A.sk_id[lane * kSlots + idx1] : -1, a_i2 = isp ? A.sk_id[lane * kSlots + idx2] : -1;
-                        const float a_f1 = isp ? A.sk_sc[lane * kSlots + idx1] : 0.0f, a_f2 = isp ? A.sk_sc[lane * kSlots + idx2] : 0.0f;
-                        const bool a1 = a_i1 > 0, a2 = a_i2 > 0;  // :200-201 id 0 counts as unassigned
-                        if (__ballot(a1 && a2) == 0) {
-                            // :203-214 running minima "min = (min == 0) ? v : min(v, min)": a plain minimum unless a value is exactly 0
-                            float min1, min2;
-                            if (__ballot((a1 && a_f1 == 0.0f) || (a2 && a_f2 == 0.0f))) {
-                                min1 = 0.0f;
-                                min2 = 0.0f;
-#pragma unroll 1
-                                for (int kp = 0; kp < PP_NUM_PART; kp++) {
-                                    const int i1 = rl(a_i1, kp), i2 = rl(a_i2, kp);
-                                    const float f1 = rlf(a_f1, kp), f2 = rlf(a_f2, kp);
-                                    if (i1 > 0) min1 = (min1 == 0.0f) ? f1 : (f1 < min1 ? f1 : min1);
-                                    if (i2 > 0) min2 = (min2 == 0.0f) ? f2 : (f2 < min2 ? f2 : min2);
-                                }
-                            } else {
-                                const float inf = __int_as_float(0x7f800000);
-                                min1 = a1 ? a_f1 : inf;
-                                min2 = a2 ? a_f2 : inf;
-#pragma unroll
-                                for (int d = 16; d >= 1; d >>= 1) {
-                                    min1 = fminf(min1, __shfl_xor(min1, d));
-                                    min2 = fminf(min2, __shfl_xor(min2, d));
-                                }
-                                min1 = rlf(min1, 0);
-                                min2 = rlf(min2, 0);
-                                if (min1 == inf) min1 = 0.0f;
-                                if (min2 == inf) min2 = 0.0f;
-                            }
-                            const float len1 = A.sk_sc[19 * kSlots + idx1];
-                            const int min_len = (int)__fmul_rn(len1, 16.0f);
-                            const float lim = __fmul_rn((min2 < min1 ? min2 : min1), 0.7f);  // :220
-                            if (u_cs >= lim || u_cl < (float)min_len) {                       // :221 OR
-                                // a limb column where BOTH rows hold an id gets their sum + 1: an id this pass's tables never saw
-                                const bool odd = __ballot((lane == part1 || lane == part2) && a_i1 >= 0 && a_i2 >= 0) != 0;
-                                const float tot = __fadd_rn(A.sk_sc[18 * kSlots + idx1], __fadd_rn(A.sk_sc[18 * kSlots + idx2], u_cs));
-                                const int cnt = A.sk_id[19 * kSlots + idx1] + A.sk_id[19 * kSlots + idx2];
-                                wave_lds_sync();
-                                if (isp) {
-                                    A.sk_id[lane * kSlots + idx1] = a_i1 + (a_i2 + 1);
-                                    A.sk_sc[lane * kSlots + idx1] = __fadd_rn(a_f1, __fadd_rn(a_f2, 1.0f));
-                                    A.sk_id[lane * kSlots + idx2] = kDeadId;  // skeletons.erase(begin + idx2), :228
-                                }
-                                if (lane == 0) {
-                                    A.sk_id[19 * kSlots + idx1] = cnt;
-                                    A.sk_sc[19 * kSlots + idx1] = len1 < u_cl ? u_cl : len1;
-                                    A.sk_sc[18 * kSlots + idx1] = tot;
-                                }
-                                wave_lds_sync();
-#pragma unroll
-                                for (int b = 0; b < kBanks; b++) {  // refresh the two owners' caches
-                                    if ((idx1 >> 6) == b && (idx1 & 63) == lane) load_cache(K[b], A, idx1, part1, part2, true);
-                                    if ((idx2 >> 6) == b && (idx2 & 63) == lane) K[b].p1 = K[b].p2 = kDeadId;
-                                }
-                                if (odd) {  // from here on every connection of this pass scans, as the reference does
-                                    confm |= next + 1 < 64 ? ~0ull << (next + 1) : 0ull;
-#pragma unroll
-                                    for (int b = 0; b < kBanks; b++) myk[b] = -1;
-                                    odd_merges++;
-                                }
-                            }
-                        }
-                    } else if (num_found == 0) {  // :257-273
-                        if (nb < kSlots) {
-                            if (lane == 0) {
-                                A.sk_id[part1 * kSlots + nb] = u_id1;
-                                A.sk_sc[part1 * kSlots + nb] = u_cs;
-                                A.sk_id[part2 * kSlots + nb] = u_id2;
-                                A.sk_sc[part2 * kSlots + nb] = u_cs;
-                                A.sk_id[19 * kSlots + nb] = 2;
-                                A.sk_sc[19 * kSlots + nb] = u_cl;
-                                A.sk_sc[18 * kSlots + nb] = __fadd_rn(__fadd_rn(u_ps1, u_ps2), u_cs);
-                            }
-                            nb++;
-                        } else {
-                            st |= PP_ST_SKEL_OVERFLOW;
-                        }
-                    }
-                    // num_found > 2: no action
-                    if (stamps) {
-                        seq_cycles += (long long)clock64() - t0;
-                        seq_conns++;
-                    }
-                }
-                pos = next + 1;
-            }
+            if (S.nb + mc > kSlots) assemble_compact(A, lane, S.nb);
+            assemble_pass<kBanks>(S, A, lane, mc, (2 * limb + 2) << 8, part1, part2, off1, off2, cnt1, cnt2, __float_as_int(ax2.x),
+                                  __float_as_int(ax2.y), cn2.z, cn2.w, ax2.z, ax2.w, stamps);
         }
     }
     wave_lds_sync();
     stamp(stamps, img, 2);
     if (stamps && lane == 0) {
-        stamps[(size_t)img * 8 + 4] = seq_conns;
-        stamps[(size_t)img * 8 + 5] = seq_cycles;
-        stamps[(size_t)img * 8 + 6] = odd_merges;
+        stamps[(size_t)img * 8 + 4] = S.seq_conns;
+        stamps[(size_t)img * 8 + 5] = S.seq_cycles;
+        stamps[(size_t)img * 8 + 6] = S.odd_merges;
+        stamps[(size_t)img * 8 + 7] = S.class_cycles;
     }
 
-    // ---- prune (:278-282) + records; survivors in slot (= birth) order
+    // ---- prune (:278-282): survivors in slot (= birth) order; their slots go to a list (the lookup tables' space is free now)
+
     int n_out = 0;
 #pragma unroll
     for (int b = 0; b < kBanks; b++) {
-        if (b * 64 >= nb) break;
+        if (b * 64 >= S.nb) break;
         const int s = b * 64 + lane;
         bool keep = false;
-        int count = 0;
-        if (s < nb && A.sk_id[s] != kDeadId) {
-            count = A.sk_id[19 * kSlots + s];
+        if (s < S.nb && A.sk_id[s] != kDeadId) {
+            const int count = A.sk_id[19 * kSlots + s];
             const float total = A.sk_sc[18 * kSlots + s];
             keep = !(count < 2 || total / (float)count < 0.45f);
         }
         const unsigned long long mk = __ballot(keep);
         if (keep) {
             const int r = n_out + __popcll(mk & lanemask_lt());
-            if (r < PP_MAX_HUMANS) {
-                pp_human *hm = rec->humans + r;
-#pragma unroll 2
-                for (int kp = 0; kp < PP_NUM_PART; kp++) {
-                    const int id = A.sk_id[kp * kSlots + s];
-                    hm->peak_id[kp] = id;
-                    int x = 0, y = 0;
-                    float sc = 0.0f;
-                    if (id >= 0 && id < n_peaks) {  // getters index the flattened peak line BY ID (:299-309)
-                        int part = kp;
-                        if (id < A.off[kp] || id >= A.off[kp + 1]) {  // an id-sum of a merge: some other part's peak
-                            part = 0;
-                            while (id >= A.off[part + 1]) part++;
-                        }
-                        const float4 p = pk_g[(size_t)part * maxp + (id - A.off[part])];
-                        x = (int)p.x;
-                        y = (int)p.y;
-                        sc = p.z;
-                    }
-                    hm->x[kp] = x;
-                    hm->y[kp] = y;
-                    hm->part_score[kp] = sc;
-                }
-                hm->score = A.sk_sc[18 * kSlots + s] / (float)count;  // get_score, :295-297
-                hm->n_parts = count;
-            }
+            if (r < PP_MAX_HUMANS) A.sk_id[18 * kSlots + r] = s;  // row 18 of the id table is unused: the kept-slot list
         }
         n_out += __popcll(mk);
     }
+
+    wave_lds_sync();
+    const int n_rec = n_out < PP_MAX_HUMANS ? n_out : PP_MAX_HUMANS;
+    // ---- records: one (human, part) item per lane step -- id from LDS, the peak's x / y / score from the peak table by ID
+    for (int i = lane; i < n_rec * PP_NUM_PART; i += 64) {
+        const int r = i / PP_NUM_PART, kp = i - r * PP_NUM_PART;
+        const int s = A.sk_id[18 * kSlots + r];
+        const int id = A.sk_id[kp * kSlots + s];
+        int x = 0, y = 0;
+        float sc = 0.0f;
+        if (id >= 0 && id < n_peaks) {  // the getters index the flattened peak line BY ID (pafprocess.cpp:299-309)
+            int part = kp;
+            if (id < A.off[kp] || id >= A.off[kp + 1]) {  // an id-sum of a merge: some other part's peak
+                part = 0;
+                while (id >= A.off[part + 1]) part++;
+            }
+            const float4 p = pk_g[(size_t)part * maxp + (id - A.off[part])];
+            x = (int)p.x;
+            y = (int)p.y;
+            sc = p.z;
+        }
+        pp_human *hm = rec->humans + r;
+        hm->peak_id[kp] = id;
+        hm->x[kp] = x;
+        hm->y[kp] = y;
+        hm->part_score[kp] = sc;
+    }
+    for (int r = lane; r < n_rec; r += 64) {
+        const int s = A.sk_id[18 * kSlots + r];
+        const int count = A.sk_id[19 * kSlots + s];
+        rec->humans[r].score = A.sk_sc[18 * kSlots + s] / (float)count;  // get_score, :295-297
+        rec->humans[r].n_parts = count;
+    }
     const unsigned fl = or_flags(flags, img, 0, lane);
     if (lane == 0) {
-        if (n_out > PP_MAX_HUMANS) {
-            st |= PP_ST_HUMAN_OVERFLOW;
-            n_out = PP_MAX_HUMANS;
-        }
-        rec->n_humans = n_out;
+        unsigned st = S.st;
+        if (n_out > PP_MAX_HUMANS) st |= PP_ST_HUMAN_OVERFLOW;
+        rec->n_humans = n_rec;
         rec->n_peaks = n_peaks;
         rec->n_connections = n_conn;
         rec->status = fl | st;
@@ -1644,8 +1694,8 @@ __global__ __launch_bounds__(64, 3) void k_assemble_wave(int maxp, const float4 
 // whole region (assemble_wave_lds_bytes).
 // Grid (30, B): workgroup (limb, position) works on image order[position] -- K_A's last workgroup sorts the images by load,
 // heaviest first, so the crowded images' limbs are dispatched first and their assembly overlaps the rest of the batch.
-// "Last block done": every limb workgroup of an image publishes its connections (stores drained by every wave, workgroup
-// barrier, one agent-scope release, one relaxed agent-scope ticket on arrive[img]); the workgroup that draws the last of
+// "Last block done": every limb workgroup of an image publishes its connections (write-through stores drained by every wave,
+// workgroup barrier, one relaxed agent-scope ticket on arrive[img]); the workgroup that draws the last of
 // the 30 tickets re-arms the counter for the next launch, acquires, and its wave 0 assembles the image while the other
 // waves leave.  No workgroup ever waits for another one, so dispatch order and residency cannot deadlock it.
 template <typename T>
@@ -1669,8 +1719,8 @@ __global__ __launch_bounds__(kThreads, 3) void k_limb_connect(const T *__restric
     const int wg = blockIdx.y * gridDim.x + blockIdx.x;
     if (nA == 0 || nB == 0) {  // no candidate pairs: no connections (pafprocess.cpp:56-58, :111)
         if (threadIdx.x == 0) {
-            *cc = 0;
-            status[img * kFlagWords + PP_NUM_PART + limb] = 0u;
+            store_sc1(cc, 0);
+            store_sc1(status + img * kFlagWords + PP_NUM_PART + limb, 0u);
         }
     } else {
         const int npix = h * w;
@@ -1723,12 +1773,11 @@ __global__ __launch_bounds__(kThreads, 3) void k_limb_connect(const T *__restric
     }
     if (!arrive) return;  // two-kernel form (timing / diagnostics): k_assemble_wave follows as its own launch
 
-    // ---- publish this limb, draw a ticket
+    // ---- publish this limb, draw a ticket.  Everything the assembly reads from this workgroup was stored write-through
+    // (store_sc1), so there is no release fence: every storing wave drains, barrier, one lane draws the ticket.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // EVERY storing wave drains its stores
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ticket must not overtake the write-back
         const int t = __hip_atomic_fetch_add(arrive + img, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = t == PP_NUM_LIMB - 1;
         if (last) __hip_atomic_store(arrive + img, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch

@@ -23,5 +23,5 @@ for dtype in (np.float16, np.float32):
         nbytes = nets.nbytes * 48 / 50
         print(f"{np.dtype(dtype).name} P={P:2d} B={B} peaks/img={rec['n_peaks'].mean():6.1f} conns/img={rec['n_connections'].mean():6.1f} "
               f"humans/img={rec['n_humans'].mean():5.1f}  K_A {ms['k_heat_peaks']*1e3:7.1f}us  K_B {ms['k_limb_connect']*1e3:7.1f}us  "
-              f"K_C {ms['k_assemble']*1e3:7.1f}us  | K_A+K_B eff {nbytes/((ms['k_heat_peaks']+ms['k_limb_connect'])*1e-3)/1e9:7.1f} GB/s "
+              f"K_C(alone) {ms['k_assemble_wave']*1e3:7.1f}us chain {ms['chain']*1e3:7.1f}us  | K_A+K_B eff {nbytes/((ms['k_heat_peaks']+ms['k_limb_connect'])*1e-3)/1e9:7.1f} GB/s "
               f"status={int(np.bitwise_or.reduce(rec['status']))}", flush=True)
