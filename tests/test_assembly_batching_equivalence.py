@@ -1,4 +1,5 @@
-"""CPU: the order-preserving batching K_C applies to person assembly (csrc/posepaf_kernels.hip k_assemble) against the plain
+"""CPU: the order-preserving batching the assembly kernels apply (csrc/posepaf_kernels.hip: k_assemble for the drop-in path,
+assemble_image_wave -- stable slots + counting classification -- for the batched path) against the plain
 connection-by-connection loop of the reference (pafprocess.cpp:138-275), both restated in Python on random inputs that are
 far nastier than real scenes (few peaks per part, so skeletons share peaks, merge, and the `id > 0` membership quirk sums
 real ids into ids that belong to other peaks).  What is checked is the ARGUMENT the kernel relies on:
@@ -141,6 +142,75 @@ def assemble_batched(conns, ps, off, cnt, stats):
     return skel
 
 
+DEAD = -2
+
+
+def assemble_wave_model(conns, ps, off, cnt, stats, slots=256):
+    """The wave form (assemble_image_wave / assemble_pass): STABLE slots (an erased skeleton's slot is marked dead, nothing
+    moves, first / second match = lowest / second-lowest live slot), classification by COUNTING -- every live skeleton looks
+    its two limb peaks up in "end point -> connection" tables and counts itself into cnt[connection] (+ a shared flag when
+    it is touched by two different connections) -- found-1 updates applied by the skeleton side, births by the connection
+    side, per maximal run of unflagged connections; the others through the scan; everything after an id-summing merge
+    through the scan."""
+    skel = []                                   # slot -> [ids, sc] or None (dead)
+    for limb, (part1, part2) in enumerate(LIMBS):
+        cs = conns[limb]
+        if not cs:
+            continue
+        cb1 = {c["id1"] - off[part1]: k for k, c in enumerate(cs)}
+        cb2 = {c["id2"] - off[part2]: k for k, c in enumerate(cs)}
+        count, shared, myk = [0] * len(cs), [False] * len(cs), {}
+        for s_, row in enumerate(skel):
+            if row is None:
+                continue
+            ids = row[0]
+            r1, r2 = ids[part1] - off[part1], ids[part2] - off[part2]
+            k1 = cb1.get(r1) if 0 <= r1 < cnt[part1] else None
+            k2 = cb2.get(r2) if 0 <= r2 < cnt[part2] else None
+            two = k1 is not None and k2 is not None and k1 != k2
+            if k1 is not None:
+                count[k1] += 1
+                shared[k1] |= two
+            if k2 is not None and k2 != k1:
+                count[k2] += 1
+                shared[k2] |= two
+            if not two and (k1 is not None or k2 is not None):
+                myk[s_] = k1 if k1 is not None else k2
+        conf = [shared[k] or count[k] >= 2 for k in range(len(cs))]
+        myk = {s_: k for s_, k in myk.items() if not conf[k]}
+        pos = 0
+        while pos < len(cs):
+            nxt = next((k for k in range(pos, len(cs)) if conf[k]), len(cs))
+            for s_, k in myk.items():           # skeleton side: found-1 updates of this run
+                if pos <= k < nxt:
+                    apply_found1(skel[s_], part2, cs[k], ps)
+            for k in range(pos, nxt):           # connection side: births in connection order
+                if count[k] == 0:
+                    skel.append(new_row(part1, part2, cs[k], ps))
+            stats["batched"] += nxt - pos
+            if nxt < len(cs):
+                c = cs[nxt]
+                live = [i for i, row in enumerate(skel) if row is not None]
+                found = [i for i in live if skel[i][0][part1] == c["id1"] or skel[i][0][part2] == c["id2"]]
+                stats["scanned"] += 1
+                if len(found) == 1:
+                    apply_found1(skel[found[0]], part2, c, ps)
+                elif len(found) == 0:
+                    skel.append(new_row(part1, part2, c, ps))
+                elif len(found) == 2:
+                    pair = [skel[found[0]], skel[found[1]]]
+                    erased, odd = scan_and_apply(pair, part1, part2, c, ps)     # the reference's two-row logic, unchanged
+                    if erased is not None:
+                        skel[found[1]] = None                                    # erase = mark dead
+                        if odd:
+                            stats["odd"] += 1
+                            conf[nxt + 1:] = [True] * (len(cs) - nxt - 1)
+                            myk = {}
+            pos = nxt + 1
+        assert len(skel) <= slots
+    return [row for row in skel if row is not None]
+
+
 def random_case(rng):
     cnt = [rng.choice([0, 1, 1, 2, 3, 5]) for _ in range(NUM_PART)]
     off, run = [], 0
@@ -178,4 +248,24 @@ def test_id_summing_merges_occur_in_the_random_cases():
     for _ in range(3000):
         conns, ps, off, cnt = random_case(rng)
         assert assemble_batched(conns, ps, off, cnt, stats) == assemble_reference(conns, ps)
+    assert stats["odd"] > 0
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_wave_form_assembly_equals_connection_by_connection(seed):
+    """the form the batched path runs (stable slots + counting classification), same random adversarial inputs"""
+    rng = random.Random(100 + seed)
+    stats = {"batched": 0, "scanned": 0, "odd": 0}
+    for _ in range(400):
+        conns, ps, off, cnt = random_case(rng)
+        assert assemble_wave_model(conns, ps, off, cnt, stats) == assemble_reference(conns, ps)
+    assert stats["batched"] > 1000 and stats["scanned"] > 300
+
+
+def test_wave_form_handles_id_summing_merges():
+    rng = random.Random(4321)
+    stats = {"batched": 0, "scanned": 0, "odd": 0}
+    for _ in range(3000):
+        conns, ps, off, cnt = random_case(rng)
+        assert assemble_wave_model(conns, ps, off, cnt, stats) == assemble_reference(conns, ps)
     assert stats["odd"] > 0

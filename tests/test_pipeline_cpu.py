@@ -44,3 +44,19 @@ def test_util_module_matches_reference_golden():
     for (x, y), want in zip(g["anchors"], g["refined"]):
         got = util.refine_centroid(g["big"], (int(x), int(y)), 2)
         assert np.allclose(np.array(got, np.float64), want, rtol=1e-6, atol=1e-7)
+
+
+def test_evaluate_buckets_images_by_padded_shape():
+    """evaluate.py batches heterogeneous image sizes per padded shape (utils/util.py:44-65 pads to /64): same padded shape ->
+    same bucket, order inside a bucket = image order, every image in exactly one bucket."""
+    import importlib.util
+    import os
+    from conftest import PKG
+    spec = importlib.util.spec_from_file_location("pp_evaluate", os.path.join(PKG, "evaluate.py"))
+    ev = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ev)
+    assert ev.padded_shape(512, 512) == (512, 512) and ev.padded_shape(427, 640) == (448, 640) and ev.padded_shape(1, 65) == (64, 128)
+    shapes = [(480, 640), (427, 640), (512, 512), (440, 600), (640, 480), (448, 640), (500, 500)]
+    g = ev.buckets_by_padded_shape(shapes)
+    assert g == {(512, 640): [0], (448, 640): [1, 3, 5], (512, 512): [2, 6], (640, 512): [4]}
+    assert sorted(k for v in g.values() for k in v) == list(range(len(shapes)))
