@@ -1,0 +1,257 @@
+// posepaf_conv_own.hip -- A1 forward: hand-written implicit-GEMM convolution for gfx950 (CDNA4) on the matrix cores,
+//   y = leaky(conv(x, w) + bias (+ residual)) (+ post)      stride 1, square kernel (1x1, 3x3, dilated), fp16 in / out,
+// fp32 accumulate -- Conv2d + folded BatchNorm + LeakyReLU (+ the residual / hourglass adds) of models/layers_transposed.py
+// (Conv :90-122, Residual :12-48, Hourglass :199-286), in ONE kernel and without composable_kernel.
+//
+// GEMM view: rows = output pixels (N*Ho*Wo, NHWC so a pixel's channels are contiguous), columns = output channels,
+// K = taps x input channels walked tap by tap in steps of 64 channels, so that every K-step of a pixel row is ONE
+// contiguous 128-byte run of the input (or the zero page when the tap falls outside the image).
+//
+// Workgroup tile 256 pixels x BN channels (BN = 256 / 128 / 64: the largest that divides C_out), 512 threads = 8 waves
+// of 64 lanes, each wave owns a (256 / WM) x 64 block of the output with v_mfma_f32_16x16x32_f16 (fp32 accumulators in
+// registers: 128 / 64 / 32 VGPRs).  Operand tiles travel HBM -> LDS by direct LDS-DMA loads (global_load_lds_dwordx4,
+// 16 B per lane, no VGPR staging), double buffered: the loads of K-step k+1 are in flight while K-step k is multiplied.
+// LDS image: 1-KiB sub-tiles of 16 rows x 32 halves; a wave's DMA instruction fills exactly one sub-tile (lane-linear
+// destination), the XOR swizzle that keeps the 16-byte fragment reads (ds_read_b128) spread over the banks is applied to
+// the per-lane SOURCE address and to the read address (cdna_hip_programming.md T2).
+// The MFMA takes the WEIGHT fragment as its A operand and the PIXEL fragment as B, so a lane's four accumulator registers
+// are four CONSECUTIVE output channels of one pixel: the epilogue (bias, residual, LeakyReLU, post add, fp16 pack) stores
+// 8 contiguous bytes per lane straight from registers, no LDS transpose.
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/posepaf.h"
+
+namespace {
+
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 256;      // output pixels per workgroup
+constexpr int BK = 64;       // input channels per K-step (one tap)
+constexpr int NTHREADS = 512;
+constexpr int SUB = 1024;    // bytes of one LDS sub-tile: 16 rows x 32 halves
+
+struct ConvParams {
+    const _Float16 *x, *w, *bias, *extra;
+    _Float16 *y;
+    const void *zero;  // >= 16 zero bytes: source of every tap that falls outside the image
+    int N, H, W, C, K, R, pad, dil, Ho, Wo;
+    long M;            // N * Ho * Wo
+    int mode;          // 0 none, 1 extra added before the activation, 2 after
+    float slope;
+};
+
+__device__ __forceinline__ void lds_dma16(const void *gsrc, unsigned char *lds_wave_base) {
+    // 64 lanes x 16 B: lane i's bytes land at lds_wave_base + 16 * i (the destination is wave-uniform, M0-based)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+template <int BN>
+__global__ __launch_bounds__(NTHREADS) void k_conv_igemm(const ConvParams p) {
+    constexpr int WN = BN / 64;          // waves along the output channels
+    constexpr int WM = 8 / WN;           // waves along the pixels
+    constexpr int PM = BM / WM;          // pixels per wave
+    constexpr int PT = PM / 16;          // 16-pixel tiles per wave
+    constexpr int CT = 4;                // 16-channel tiles per wave
+    constexpr int A_BYTES = BM * BK * 2;
+    constexpr int B_BYTES = BN * BK * 2;
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    constexpr int BSUB = (BN / 16 * 2) / 8;  // weight sub-tiles each wave stages per K-step: 4 / 2 / 1
+    extern __shared__ __align__(16) unsigned char smem[];  // 2 stages x (pixel tile | weight tile)
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const long m0 = (long)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+
+    // ---- this lane's place in a DMA'd sub-tile (swizzle on the source side)
+    const int b = lane * 16;
+    const int bs = b ^ (((b >> 9) & 1) << 5);
+    const int row_in = bs >> 6;   // 0..15
+    const int kbyte = bs & 63;    // byte offset inside the 32-half k slice
+    // pixel rows this lane fetches: sub-tiles wave*4 .. wave*4+3 = row blocks 2*wave, 2*wave+1, both k halves each
+    int oy[2], ox[2];
+    long xoff[2];
+    bool rowok[2];
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const long m = m0 + (wave * 2 + i) * 16 + row_in;
+        rowok[i] = m < p.M;
+        const long mm = rowok[i] ? m : 0;
+        const int n = (int)(mm / HoWo);
+        const int rem = (int)(mm - (long)n * HoWo);
+        oy[i] = rem / p.Wo;
+        ox[i] = rem - oy[i] * p.Wo;
+        xoff[i] = (((long)n * p.H + oy[i]) * p.W + ox[i]) * p.C * 2 + kbyte;
+    }
+    // weight rows this lane fetches
+    long woff[BSUB];
+    const long wrow = (long)p.R * p.R * p.C * 2;  // bytes per output channel
+#pragma unroll
+    for (int j = 0; j < BSUB; j++) {
+        const int s = wave * BSUB + j;
+        woff[j] = (long)(n0 + (s >> 1) * 16 + row_in) * wrow + (s & 1) * 64 + kbyte;
+    }
+    const int kc = p.C / BK;          // K-steps per tap
+    const int nk = p.R * p.R * kc;    // K-steps in all
+    const char *xb = reinterpret_cast<const char *>(p.x);
+    const char *wb = reinterpret_cast<const char *>(p.w);
+    const char *zp = reinterpret_cast<const char *>(p.zero);
+
+    int st_r = 0, st_s = 0, st_c = 0;  // tap / channel block of the NEXT K-step to stage
+    auto stage = [&](int buf) {
+        unsigned char *sa = smem + buf * STAGE;
+        const int dy = st_r * p.dil - p.pad, dx = st_s * p.dil - p.pad;
+        const long tapoff = ((long)dy * p.W + dx) * p.C * 2 + (long)st_c * (BK * 2);
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const bool ok = rowok[i] && (unsigned)(oy[i] + dy) < (unsigned)p.H && (unsigned)(ox[i] + dx) < (unsigned)p.W;
+            const char *src = xb + xoff[i] + tapoff;
+            lds_dma16(ok ? src : zp, sa + ((wave * 2 + i) * 2 + 0) * SUB);
+            lds_dma16(ok ? src + 64 : zp, sa + ((wave * 2 + i) * 2 + 1) * SUB);
+        }
+        const long wk = ((long)(st_r * p.R + st_s) * p.C + (long)st_c * BK) * 2;
+#pragma unroll
+        for (int j = 0; j < BSUB; j++) lds_dma16(wb + woff[j] + wk, sa + A_BYTES + (wave * BSUB + j) * SUB);
+        if (++st_c == kc) {
+            st_c = 0;
+            if (++st_s == p.R) {
+                st_s = 0;
+                ++st_r;
+            }
+        }
+    };
+
+    float4_t acc[PT][CT];
+#pragma unroll
+    for (int i = 0; i < PT; i++)
+#pragma unroll
+        for (int j = 0; j < CT; j++) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offset inside a sub-tile: row = lane & 15, k group = lane >> 4 (8 halves = 16 B), swizzled like the source
+    const int fragoff = (lane & 15) * 64 + (((lane >> 4) * 16) ^ (((lane & 15) >> 3) << 5));
+
+    stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt++) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(cur ^ 1);  // next K-step's loads fly while this one is multiplied
+        const unsigned char *sa = smem + cur * STAGE;
+        const unsigned char *sb = sa + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            half8_t wf[CT], xf[PT];
+#pragma unroll
+            for (int j = 0; j < CT; j++)
+                wf[j] = *reinterpret_cast<const half8_t *>(sb + ((wn * 4 + j) * 2 + ks) * SUB + fragoff);
+#pragma unroll
+            for (int i = 0; i < PT; i++)
+                xf[i] = *reinterpret_cast<const half8_t *>(sa + ((wm * PT + i) * 2 + ks) * SUB + fragoff);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < PT; i++)
+#pragma unroll
+                for (int j = 0; j < CT; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        __syncthreads();  // drains the DMA (vmcnt(0)) and makes the next stage visible; also fences the buffer just read
+    }
+
+    // ---- epilogue from registers: lane holds, per (pixel tile, channel tile), 4 consecutive channels of one pixel
+    const int cq = (lane >> 4) * 4;
+    half4_t bv[CT];
+#pragma unroll
+    for (int j = 0; j < CT; j++) bv[j] = *reinterpret_cast<const half4_t *>(p.bias + n0 + wn * 64 + j * 16 + cq);
+#pragma unroll
+    for (int i = 0; i < PT; i++) {
+        const long m = m0 + wm * PM + i * 16 + (lane & 15);
+        if (m < p.M) {
+#pragma unroll
+            for (int j = 0; j < CT; j++) {
+                const long o = m * p.K + n0 + wn * 64 + j * 16 + cq;
+                half4_t ev = half4_t{0, 0, 0, 0};
+                if (p.mode) ev = *reinterpret_cast<const half4_t *>(p.extra + o);
+                half4_t out;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float v = acc[i][j][e] + (float)bv[j][e];
+                    if (p.mode == 1) v += (float)ev[e];
+                    v = v > 0.f ? v : v * p.slope;
+                    if (p.mode == 2) v += (float)ev[e];
+                    out[e] = (_Float16)v;
+                }
+                *reinterpret_cast<half4_t *>(p.y + o) = out;
+            }
+        }
+    }
+}
+
+void *g_zero_page = nullptr;
+
+template <int BN>
+int launch(const ConvParams &p, hipStream_t st) {
+    constexpr int lds = 2 * (BM * BK * 2 + BN * BK * 2);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_igemm<BN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+            hipSuccess)
+            return PP_ERR_HIP;
+        attr_done = true;
+    }
+    const dim3 grid((unsigned)((p.M + BM - 1) / BM), (unsigned)(p.K / BN));
+    hipLaunchKernelGGL(k_conv_igemm<BN>, grid, dim3(NTHREADS), lds, st, p);
+    return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
+}
+
+}  // namespace
+
+extern "C" {
+
+// 1 when pp_conv_own_f16 takes the shape: stride 1, square kernel, C_in % 64 == 0, C_out % 64 == 0
+PP_API int pp_conv_own_supported(int c_in, int c_out, int ksize) { return (c_in % 64 == 0 && c_out % 64 == 0 && ksize >= 1 && ksize <= 7) ? 1 : 0; }
+
+PP_API int pp_conv_own_f16(const void *x, const void *w, const void *bias, const void *extra, void *y, int n, int h, int wd, int c_in,
+                    int c_out, int ksize, int pad, int dilation, int extra_mode, float slope, int bn, void *stream) {
+    if (!x || !w || !bias || !y || n <= 0 || h <= 0 || wd <= 0 || ksize <= 0 || pad < 0 || dilation <= 0 || extra_mode < 0 ||
+        extra_mode > 2 || (extra_mode != 0) != (extra != nullptr))
+        return PP_ERR_BAD_ARG;
+    if (!pp_conv_own_supported(c_in, c_out, ksize)) return PP_ERR_UNSUPPORTED;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(bias) |
+                         reinterpret_cast<uintptr_t>(extra) | reinterpret_cast<uintptr_t>(y);
+    if (al & 15) return PP_ERR_BAD_ARG;
+    const int ho = h + 2 * pad - dilation * (ksize - 1), wo = wd + 2 * pad - dilation * (ksize - 1);
+    if (ho <= 0 || wo <= 0) return PP_ERR_BAD_ARG;
+    if (bn == 0) bn = c_out % 256 == 0 ? 256 : (c_out % 128 == 0 ? 128 : 64);
+    if ((bn != 256 && bn != 128 && bn != 64) || c_out % bn) return PP_ERR_UNSUPPORTED;
+    if (!g_zero_page) {
+        if (hipMalloc(&g_zero_page, 256) != hipSuccess || hipMemset(g_zero_page, 0, 256) != hipSuccess) return PP_ERR_HIP;
+    }
+    ConvParams p;
+    p.x = static_cast<const _Float16 *>(x);
+    p.w = static_cast<const _Float16 *>(w);
+    p.bias = static_cast<const _Float16 *>(bias);
+    p.extra = static_cast<const _Float16 *>(extra);
+    p.y = static_cast<_Float16 *>(y);
+    p.zero = g_zero_page;
+    p.N = n; p.H = h; p.W = wd; p.C = c_in; p.K = c_out; p.R = ksize; p.pad = pad; p.dil = dilation; p.Ho = ho; p.Wo = wo;
+    p.M = (long)n * ho * wo;
+    p.mode = extra_mode;
+    p.slope = slope;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (bn) {
+        case 256: return launch<256>(p, st);
+        case 128: return launch<128>(p, st);
+        default: return launch<64>(p, st);
+    }
+}
+
+}  // extern "C"

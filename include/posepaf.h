@@ -183,6 +183,15 @@ PP_API int pp_conv_f16(const void *x, const void *w, const void *bias, const voi
                        int c_in, int c_out, int ksize, int pad, int dilation, int extra_mode, float slope, int config,
                        void *stream);
 
+/* A1 forward: the same fused convolution as pp_conv_f16 -- identical arguments and semantics -- as a HAND-WRITTEN implicit-GEMM
+ * kernel (csrc/posepaf_conv_own.hip: 256-pixel x bn-channel workgroup tiles, LDS-DMA staging, v_mfma_f32_16x16x32_f16, epilogue
+ * from registers; no composable_kernel).  Needs c_in % 64 == 0 and c_out % 64 == 0 (pp_conv_own_supported).  bn = output
+ * channels per workgroup: 256, 128 or 64 (must divide c_out), 0 = the largest that divides c_out. */
+PP_API int pp_conv_own_supported(int c_in, int c_out, int ksize);
+PP_API int pp_conv_own_f16(const void *x, const void *w, const void *bias, const void *extra, void *y, int n, int h, int wd,
+                           int c_in, int c_out, int ksize, int pad, int dilation, int extra_mode, float slope, int bn,
+                           void *stream);
+
 /* A0 pre-processing (utils/parse_skeletons.py:52-73, utils/util.py:44-65) of a batch of equally sized BGR uint8 DEVICE
  * images (batch, h, w, 3): pad bottom/right to a multiple of pad_to with pad_value, divide by 255, and write each image
  * followed (flip != 0) by the W-mirror of the PADDED image.  out: DEVICE (batch*(flip?2:1), Hp, Wp, 3), PP_F16 or PP_F32. */

@@ -211,3 +211,54 @@ def test_evaluate_script_with_two_image_sizes(tmp_path):
         assert summary["people_found"] == len(res) >= 7 * 2 - 2
         assert sorted({r_["image_id"] for r_ in res}) == list(range(7))
         assert summary["synthetic_oks"]["AP"] > 0.5, summary
+
+
+@pytest.mark.parametrize("shape", [
+    # n, c_in, c_out, h, w, ksize, pad, dilation
+    (2, 64, 64, 32, 32, 3, 1, 1),        # BN = 64
+    (1, 128, 128, 24, 40, 3, 3, 3),      # the dilated 3x3 of the feature heads, BN = 128
+    (2, 256, 256, 16, 24, 3, 1, 1),      # the hot layer's shape family, BN = 256
+    (2, 256, 128, 16, 16, 1, 0, 1),      # 1x1
+    (1, 192, 384, 8, 8, 1, 0, 1),        # 1x1, BN = 128, three channel tiles
+    (3, 64, 192, 9, 7, 3, 1, 1),         # ragged pixel count (189 rows: a partial 256-row tile), BN = 64 x 3
+    (1, 320, 640, 5, 6, 3, 1, 1),        # more K-steps than pixels
+])
+def test_own_implicit_gemm_convolution_matches_torch(shape):
+    """pp_conv_own_f16 (hand-written LDS-DMA + MFMA implicit GEMM, csrc/posepaf_conv_own.hip) against an fp32 torch convolution
+    of the same fp16 operands, every epilogue variant and every workgroup-tile width that divides c_out.  ASYMMETRIC random
+    operands; fp32 accumulate, fp16 store: tolerance 2e-3 relative to the output scale (same bar as the template kernels)."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from posepaf import _lib
+    L = _lib.load()
+    n, ci, co, h, w, k, pad, dil = shape
+    assert L.pp_conv_own_supported(ci, co, k) == 1
+    g = torch.Generator(device="cpu").manual_seed(11)
+    x = torch.randn(n, ci, h, w, generator=g).cuda().half().contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5).cuda().half().contiguous(memory_format=torch.channels_last)
+    b = torch.randn(co, generator=g).cuda().half()
+    ho, wo = h + 2 * pad - dil * (k - 1), w + 2 * pad - dil * (k - 1)
+    ex = torch.randn(n, co, ho, wo, generator=g).cuda().half().contiguous(memory_format=torch.channels_last)
+    conv = F.conv2d(x.float(), wt.float(), b.float(), 1, pad, dil)
+    vp = C.c_void_p
+    stream = vp(torch.cuda.current_stream().cuda_stream)
+    ran = 0
+    for mode, slope in [(0, 0.01), (1, 0.01), (2, 0.01), (0, 1.0), (1, 1.0)]:
+        ref = conv + ex.float() if mode == 1 else conv
+        ref = F.leaky_relu(ref, slope) if slope != 1.0 else ref
+        ref = ref + ex.float() if mode == 2 else ref
+        for bn in (0, 256, 128, 64):
+            y = torch.full((n, co, ho, wo), float("nan"), dtype=torch.float16, device="cuda").contiguous(memory_format=torch.channels_last)
+            rc = L.pp_conv_own_f16(vp(x.data_ptr()), vp(wt.data_ptr()), vp(b.data_ptr()), vp(ex.data_ptr()) if mode else None,
+                                   vp(y.data_ptr()), n, h, w, ci, co, k, pad, dil, mode, slope, bn, stream)
+            if rc == -6:
+                assert bn and co % bn      # only a tile width that does not divide c_out may be refused
+                continue
+            assert rc == 0, (bn, mode, rc)
+            torch.cuda.synchronize()
+            assert torch.isfinite(y).all(), (shape, bn, mode)
+            err = (y.float() - ref).abs().max().item()
+            assert err <= 2e-3 * max(1.0, ref.abs().max().item()), (shape, bn, mode, slope, err)
+            ran += 1
+    assert ran >= 10
+    assert L.pp_conv_own_supported(72, 64, 3) == 0 and L.pp_conv_own_supported(64, 40, 3) == 0
