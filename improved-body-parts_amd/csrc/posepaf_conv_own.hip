@@ -31,7 +31,6 @@ typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 typedef float float4_t __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 256;      // output pixels per workgroup
-constexpr int BK = 64;       // input channels per K-step (one tap)
 constexpr int NTHREADS = 512;
 constexpr int SUB = 1024;    // bytes of one LDS sub-tile: 16 rows x 32 halves
 
@@ -51,6 +50,15 @@ __device__ __forceinline__ void lds_dma16(const void *gsrc, unsigned char *lds_w
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// K loop in PHASES of 32 input channels.  Four phase buffers in LDS (pixel slice 256 x 32 + weight slice BN x 32 halves each);
+// while phase p is multiplied, the LDS-DMA loads of phases p+1 and p+2 are in flight and those of phase p+3 are issued into the
+// buffer phase p-1 used (every wave is past its phase p-1 reads once it has left the barrier that opens phase p).  One raw
+// s_barrier per phase, counted vmcnt (never 0 inside the loop): the DMA stays in flight ACROSS barriers.
 template <int BN>
 __global__ __launch_bounds__(NTHREADS) void k_conv_igemm(const ConvParams p) {
     constexpr int WN = BN / 64;          // waves along the output channels
@@ -58,11 +66,13 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_igemm(const ConvParams p) {
     constexpr int PM = BM / WM;          // pixels per wave
     constexpr int PT = PM / 16;          // 16-pixel tiles per wave
     constexpr int CT = 4;                // 16-channel tiles per wave
-    constexpr int A_BYTES = BM * BK * 2;
-    constexpr int B_BYTES = BN * BK * 2;
-    constexpr int STAGE = A_BYTES + B_BYTES;
-    constexpr int BSUB = (BN / 16 * 2) / 8;  // weight sub-tiles each wave stages per K-step: 4 / 2 / 1
-    extern __shared__ __align__(16) unsigned char smem[];  // 2 stages x (pixel tile | weight tile)
+    constexpr int A_BYTES = BM * 32 * 2;         // pixel slice of one phase: 16 sub-tiles
+    constexpr int B_BYTES = BN * 32 * 2;         // weight slice of one phase: BN / 16 sub-tiles
+    constexpr int PBUF = A_BYTES + B_BYTES;
+    constexpr int NBUF = 4;
+    constexpr int BL = BN == 256 ? 2 : 1;        // weight sub-tiles each wave stages per phase (BN = 64: waves 4..7 repeat 0..3)
+    constexpr int NL = 2 + BL;                   // DMA instructions per wave and phase
+    extern __shared__ __align__(16) unsigned char smem[];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -75,7 +85,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_igemm(const ConvParams p) {
     const int bs = b ^ (((b >> 9) & 1) << 5);
     const int row_in = bs >> 6;   // 0..15
     const int kbyte = bs & 63;    // byte offset inside the 32-half k slice
-    // pixel rows this lane fetches: sub-tiles wave*4 .. wave*4+3 = row blocks 2*wave, 2*wave+1, both k halves each
+    // pixel rows this lane fetches: row blocks 2*wave and 2*wave+1
     int oy[2], ox[2];
     long xoff[2];
     bool rowok[2];
@@ -92,35 +102,36 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_igemm(const ConvParams p) {
         xoff[i] = (((long)n * p.H + oy[i]) * p.W + ox[i]) * p.C * 2 + kbyte;
     }
     // weight rows this lane fetches
-    long woff[BSUB];
+    long woff[BL];
+    int wsub[BL];
     const long wrow = (long)p.R * p.R * p.C * 2;  // bytes per output channel
 #pragma unroll
-    for (int j = 0; j < BSUB; j++) {
-        const int s = wave * BSUB + j;
-        woff[j] = (long)(n0 + (s >> 1) * 16 + row_in) * wrow + (s & 1) * 64 + kbyte;
+    for (int j = 0; j < BL; j++) {
+        wsub[j] = BN == 256 ? wave * 2 + j : (BN == 128 ? wave : (wave & 3));
+        woff[j] = (long)(n0 + wsub[j] * 16 + row_in) * wrow + kbyte;
     }
-    const int kc = p.C / BK;          // K-steps per tap
-    const int nk = p.R * p.R * kc;    // K-steps in all
+    const int kc2 = p.C / 32;           // phases per tap
+    const int np = p.R * p.R * kc2;     // phases in all
     const char *xb = reinterpret_cast<const char *>(p.x);
     const char *wb = reinterpret_cast<const char *>(p.w);
     const char *zp = reinterpret_cast<const char *>(p.zero);
 
-    int st_r = 0, st_s = 0, st_c = 0;  // tap / channel block of the NEXT K-step to stage
+    int st_r = 0, st_s = 0, st_c = 0;  // tap / 32-channel block of the NEXT phase to stage
     auto stage = [&](int buf) {
-        unsigned char *sa = smem + buf * STAGE;
+        unsigned char *sa = smem + buf * PBUF;
         const int dy = st_r * p.dil - p.pad, dx = st_s * p.dil - p.pad;
-        const long tapoff = ((long)dy * p.W + dx) * p.C * 2 + (long)st_c * (BK * 2);
+        const long tapoff = ((long)dy * p.W + dx) * p.C * 2 + (long)st_c * 64;
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             const bool ok = rowok[i] && (unsigned)(oy[i] + dy) < (unsigned)p.H && (unsigned)(ox[i] + dx) < (unsigned)p.W;
-            const char *src = xb + xoff[i] + tapoff;
-            lds_dma16(ok ? src : zp, sa + ((wave * 2 + i) * 2 + 0) * SUB);
-            lds_dma16(ok ? src + 64 : zp, sa + ((wave * 2 + i) * 2 + 1) * SUB);
+            const uintptr_t src = reinterpret_cast<uintptr_t>(xb) + (uintptr_t)(xoff[i] + tapoff);
+            const uintptr_t sel = ok ? src : reinterpret_cast<uintptr_t>(zp);  // a select, not a branch: ONE DMA per sub-tile
+            lds_dma16(reinterpret_cast<const void *>(sel), sa + (wave * 2 + i) * SUB);
         }
-        const long wk = ((long)(st_r * p.R + st_s) * p.C + (long)st_c * BK) * 2;
+        const long wk = ((long)(st_r * p.R + st_s) * p.C) * 2 + (long)st_c * 64;
 #pragma unroll
-        for (int j = 0; j < BSUB; j++) lds_dma16(wb + woff[j] + wk, sa + A_BYTES + (wave * BSUB + j) * SUB);
-        if (++st_c == kc) {
+        for (int j = 0; j < BL; j++) lds_dma16(wb + woff[j] + wk, sa + A_BYTES + wsub[j] * SUB);
+        if (++st_c == kc2) {
             st_c = 0;
             if (++st_s == p.R) {
                 st_s = 0;
@@ -138,33 +149,43 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_igemm(const ConvParams p) {
     // fragment read offset inside a sub-tile: row = lane & 15, k group = lane >> 4 (8 halves = 16 B), swizzled like the source
     const int fragoff = (lane & 15) * 64 + (((lane >> 4) * 16) ^ (((lane & 15) >> 3) << 5));
 
-    stage(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int kt = 0; kt < nk; kt++) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) stage(cur ^ 1);  // next K-step's loads fly while this one is multiplied
-        const unsigned char *sa = smem + cur * STAGE;
+    // prologue: three phases on their way; phase 0 landed for everybody
+    const int grp = wave >> 2;  // waves w and w + 4 share a SIMD: the two groups run half a phase apart (see the loop)
+    for (int q = 0; q < 3 && q < np; q++) stage(q);
+    if (np >= 3) wait_vmcnt<2 * NL>();
+    else if (np == 2) wait_vmcnt<NL>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    // Two sections per phase, a barrier after each: LOAD (issue the DMA of phase ph+3, read this phase's fragments from LDS,
+    // retire the own DMA of phase ph+1) and MULTIPLY (32 MFMAs per wave).  Group 1 runs one barrier behind group 0, so on
+    // every SIMD one wave multiplies while its partner loads: the matrix pipe does not wait for LDS / DMA issue.
+    // Buffer (ph+3)&3 is the one phase ph-1 used; both groups finished reading it before the barrier that lets either of
+    // them get here.  Phase ph+1's bytes are retired by EVERY wave one full phase before anyone reads them.
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    for (int ph = 0; ph < np; ph++) {
+        if (ph + 3 < np) stage((ph + 3) & (NBUF - 1));
+        const unsigned char *sa = smem + (ph & (NBUF - 1)) * PBUF;
         const unsigned char *sb = sa + A_BYTES;
+        half8_t wf[CT], xf[PT];
 #pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-            half8_t wf[CT], xf[PT];
+        for (int j = 0; j < CT; j++) wf[j] = *reinterpret_cast<const half8_t *>(sb + (wn * 4 + j) * SUB + fragoff);
 #pragma unroll
-            for (int j = 0; j < CT; j++)
-                wf[j] = *reinterpret_cast<const half8_t *>(sb + ((wn * 4 + j) * 2 + ks) * SUB + fragoff);
+        for (int i = 0; i < PT; i++) xf[i] = *reinterpret_cast<const half8_t *>(sa + (wm * PT + i) * SUB + fragoff);
+        const int inflight = np - 1 - ph < 3 ? np - 1 - ph : 3;  // DMA groups of later phases outstanding now
+        if (inflight == 3) wait_vmcnt<2 * NL>();
+        else if (inflight == 2) wait_vmcnt<NL>();
+        else if (inflight == 1) wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int i = 0; i < PT; i++)
-                xf[i] = *reinterpret_cast<const half8_t *>(sa + ((wm * PT + i) * 2 + ks) * SUB + fragoff);
-            __builtin_amdgcn_s_setprio(1);
+        for (int i = 0; i < PT; i++)
 #pragma unroll
-            for (int i = 0; i < PT; i++)
-#pragma unroll
-                for (int j = 0; j < CT; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-        }
-        __syncthreads();  // drains the DMA (vmcnt(0)) and makes the next stage visible; also fences the buffer just read
+            for (int j = 0; j < CT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
     }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
 
     // ---- epilogue from registers: lane holds, per (pixel tile, channel tile), 4 consecutive channels of one pixel
     const int cq = (lane >> 4) * 4;
@@ -199,7 +220,7 @@ void *g_zero_page = nullptr;
 
 template <int BN>
 int launch(const ConvParams &p, hipStream_t st) {
-    constexpr int lds = 2 * (BM * BK * 2 + BN * BK * 2);
+    constexpr int lds = 4 * (BM * 32 * 2 + BN * 32 * 2);  // four phase buffers
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_igemm<BN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
@@ -217,7 +238,7 @@ int launch(const ConvParams &p, hipStream_t st) {
 extern "C" {
 
 // 1 when pp_conv_own_f16 takes the shape: stride 1, square kernel, C_in % 64 == 0, C_out % 64 == 0
-PP_API int pp_conv_own_supported(int c_in, int c_out, int ksize) { return (c_in % 64 == 0 && c_out % 64 == 0 && ksize >= 1 && ksize <= 7) ? 1 : 0; }
+PP_API int pp_conv_own_supported(int c_in, int c_out, int ksize) { return (c_in % 32 == 0 && c_out % 64 == 0 && ksize >= 1 && ksize <= 7) ? 1 : 0; }
 
 PP_API int pp_conv_own_f16(const void *x, const void *w, const void *bias, const void *extra, void *y, int n, int h, int wd, int c_in,
                     int c_out, int ksize, int pad, int dilation, int extra_mode, float slope, int bn, void *stream) {
