@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "../../include/posepaf.h"
 
@@ -42,6 +43,8 @@ struct ConvParams {
     long M;            // N * Ho * Wo
     int mode;          // 0 none, 1 extra added before the activation, 2 after
     float slope;
+    int dbg;           // ablation switches (POSEPAF_CONV_DBG, diagnostics only): 1 no DMA in the loop, 2 no MFMA, 4 no fragment
+                       // reads, 8 no epilogue stores.  0 in production.
 };
 
 __device__ __forceinline__ void lds_dma16(const void *gsrc, unsigned char *lds_wave_base) {
@@ -216,7 +219,231 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_igemm(const ConvParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ 3x3, halo tile in LDS
+// The implicit-GEMM kernel above loads the pixel operand once PER TAP: nine times the same bytes, shifted.  A CU's load path
+// (HBM / L2 -> LDS, ~12-20 B per clock) is what bounds it, not the matrix pipe.  For the 3x3 / pad = dilation = 1 layers --
+// 90 % of the forward's convolution time -- this kernel loads each input pixel ONCE per 32-channel block: the workgroup's
+// output tile is a TH x TW block of ONE image (512 pixels), its (TH+2) x (TW+2) input halo for the current channel block sits
+// in LDS (double buffered: the next block's halo streams in during the nine taps of this one), and the nine taps are nine
+// K-steps whose pixel fragments are read from the same halo at shifted pixel offsets.  Only the weights still stream per tap:
+// BN = 128 output channels x 32 halves = 8 KiB per phase, next to ~5.6 KiB of halo, instead of 32 KiB per phase above.
+// 8 waves as 4 (pixels) x 2 (channels), 128 x 64 outputs per wave (128 accumulator VGPRs), v_mfma_f32_16x16x32_f16 with the
+// weight fragment as A and the pixel fragment as B as above; same four-slot weight ring, counted vmcnt, raw barriers and
+// half-phase stagger between the two waves of each SIMD.
+constexpr int TP = 512;  // output pixels per workgroup
+
+struct HaloParams {
+    int TW, TH, lgTW;       // tile width (power of two, <= 128), height = 512 / TW
+    int tiles_x, tiles;     // tiles per image row / per image
+    int HWp, nhalo, npieces;  // halo row length TW + 2, halo pixels, 16-pixel DMA pieces (last one padded)
+};
+
+template <int BN, bool ABLATE>
+__global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, const HaloParams hp) {
+    const int dbg = ABLATE ? p.dbg : 0;  // compile-time 0 in the production instance
+    constexpr int WN = BN / 64;          // 2
+    constexpr int WM = 8 / WN;           // 4
+    constexpr int PM = TP / WM;          // 128 pixels per wave
+    constexpr int PT = PM / 16;          // 8
+    constexpr int CT = 4;
+    constexpr int WB = BN * 32 * 2;      // weight slice of one phase
+    constexpr int NL = 2;                // DMA instructions per wave and phase: one halo piece (or a dummy), one weight sub-tile
+    static_assert(BN == 128, "one weight sub-tile per wave and phase");
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int halo_bytes = hp.npieces * SUB;
+    unsigned char *s_halo = smem;                               // [2][npieces * 1 KiB]
+    unsigned char *s_w = smem + 2 * halo_bytes;                 // [4][WB]
+    unsigned char *s_dummy = s_w + 4 * WB;                      // [8][1 KiB] landing zone of the padding DMAs
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int n_img = blockIdx.x / hp.tiles, tile = blockIdx.x - n_img * hp.tiles;
+    const int ty0 = (tile / hp.tiles_x) * hp.TH, tx0 = (tile - (tile / hp.tiles_x) * hp.tiles_x) * hp.TW;
+    const int n0 = blockIdx.y * BN;
+    const char *xb = reinterpret_cast<const char *>(p.x);
+    const char *wb = reinterpret_cast<const char *>(p.w);
+    const char *zp = reinterpret_cast<const char *>(p.zero);
+
+    // ---- halo DMA sources.  A piece is 16 halo pixels x 64 B, lane-linear in LDS; the swizzle (bit 5 ^= bit 9 of the byte
+    // address inside the halo buffer) is applied on the source side.  Wave w loads pieces w, w+8, ..., w+48 (7 per channel
+    // block, one per tap 0..6); taps 7 and 8 issue a dummy so that every phase has the same DMA count.
+    long hsrc[7];   // byte offset into x for channel block 0, or -1: zero page (outside the image / past the halo)
+#pragma unroll
+    for (int t = 0; t < 7; t++) {
+        const int piece = t * 8 + wave;
+        const int phys = piece * SUB + lane * 16;
+        const int logical = phys ^ (((phys >> 9) & 1) << 5);
+        const int hpix = logical >> 6, chunk = (logical >> 4) & 3;
+        const int hy = hpix / hp.HWp, hx = hpix - hy * hp.HWp;
+        const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+        const bool ok = piece < hp.npieces && hpix < hp.nhalo && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        hsrc[t] = ok ? ((((long)n_img * p.H + iy) * p.W + ix) * p.C * 2 + chunk * 16) : -1;
+    }
+    // weight sub-tile of this wave: 16 output channels x 32 halves per phase
+    const int b = lane * 16;
+    const int bs = b ^ (((b >> 9) & 1) << 5);
+    const long wrow = 9L * p.C * 2;
+    const long woff = (long)(n0 + wave * 16 + (bs >> 6)) * wrow + (bs & 63);
+
+    const int ncb = p.C / 32;
+    const int np = ncb * 9;
+    int st_cb = 0, st_tap = 0;   // (channel block, tap) of the NEXT weight slice to stage
+    auto stage_w = [&](int slot) {
+        lds_dma16(wb + woff + ((long)st_tap * p.C + (long)st_cb * 32) * 2, s_w + slot * WB + wave * SUB);
+        if (++st_tap == 9) {
+            st_tap = 0;
+            ++st_cb;
+        }
+    };
+    auto stage_halo = [&](int t, int cb, int buf) {   // piece t*8+wave of channel block cb into halo buffer buf; t >= 7: dummy
+        if (t < 7 && t * 8 + wave < hp.npieces) {
+            long off = -1;
+#pragma unroll
+            for (int q = 0; q < 7; q++) off = t == q ? hsrc[q] : off;
+            const uintptr_t src = off >= 0 ? reinterpret_cast<uintptr_t>(xb) + (uintptr_t)(off + (long)cb * 64) : reinterpret_cast<uintptr_t>(zp);
+            lds_dma16(reinterpret_cast<const void *>(src), s_halo + buf * halo_bytes + (t * 8 + wave) * SUB);
+        } else {
+            lds_dma16(zp, s_dummy + wave * SUB);
+        }
+    };
+
+    float4_t acc[PT][CT];
+#pragma unroll
+    for (int i = 0; i < PT; i++)
+#pragma unroll
+        for (int j = 0; j < CT; j++) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+    // fragment addresses.  Weights: sub-tile image as above.  Pixels: lane reads 16 B (k group g) of halo pixel
+    // (qy + r) * HWp + qx + s for its output pixel q; hb[i] is the tap-(0,0) byte address, the tap adds a uniform offset.
+    const int wfrag = (lane & 15) * 64 + (((lane >> 4) * 16) ^ (((lane & 15) >> 3) << 5));
+    int hb[PT];
+#pragma unroll
+    for (int i = 0; i < PT; i++) {
+        const int q = wm * PM + i * 16 + (lane & 15);
+        const int qy = q >> hp.lgTW, qx = q & (hp.TW - 1);
+        hb[i] = (qy * hp.HWp + qx) * 64 + (lane >> 4) * 16;
+    }
+
+    // ---- prologue: halo of channel block 0 (7 pieces per wave) and the weights of phases 0..2; everything landed
+    for (int t = 0; t < 7; t++) stage_halo(t, 0, 0);
+    for (int q = 0; q < 3 && q < np; q++) stage_w(q);
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    const int grp = wave >> 2;
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    int cb = 0, tap = 0;
+    for (int ph = 0; ph < np; ph++) {
+        // LOAD section: DMA of this phase (halo piece of the NEXT channel block first, then the weight slice of phase ph+3)
+        if (!(dbg & 1)) {
+            if (cb + 1 < ncb) stage_halo(tap, cb + 1, (cb + 1) & 1);
+            else lds_dma16(zp, s_dummy + wave * SUB);
+            if (ph + 3 < np) stage_w((ph + 3) & 3);
+            else lds_dma16(zp, s_dummy + wave * SUB);
+        }
+        const int r = tap / 3, sx = tap - r * 3;
+        const int tapoff = (r * hp.HWp + sx) * 64;
+        const unsigned char *sh = s_halo + (cb & 1) * halo_bytes;
+        const unsigned char *sw = s_w + (ph & 3) * WB;
+        half8_t wf[CT], xf[PT];
+        if (!(dbg & 4) || ph == 0) {
+#pragma unroll
+            for (int j = 0; j < CT; j++) wf[j] = *reinterpret_cast<const half8_t *>(sw + (wn * 4 + j) * SUB + wfrag);
+#pragma unroll
+            for (int i = 0; i < PT; i++) {
+                const int L = hb[i] + tapoff;
+                xf[i] = *reinterpret_cast<const half8_t *>(sh + (L ^ ((L >> 4) & 32)));
+            }
+        }
+        // retire this wave's DMA up to the weight slice of phase ph+1 (and every halo piece issued two phases ago or earlier):
+        // the two newest phases' instructions (2 x NL) may stay in flight
+        wait_vmcnt<2 * NL>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // MULTIPLY section
+        if (!(dbg & 2)) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < PT; i++)
+#pragma unroll
+                for (int j = 0; j < CT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        __builtin_amdgcn_s_barrier();
+        if (++tap == 9) {
+            tap = 0;
+            ++cb;
+        }
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+    wait_vmcnt<0>();   // the trailing dummies
+
+    // ---- epilogue from registers
+    const int cq = (lane >> 4) * 4;
+    half4_t bv[CT];
+#pragma unroll
+    for (int j = 0; j < CT; j++) bv[j] = *reinterpret_cast<const half4_t *>(p.bias + n0 + wn * 64 + j * 16 + cq);
+#pragma unroll
+    for (int i = 0; i < PT; i++) {
+        const int q = wm * PM + i * 16 + (lane & 15);
+        const int qy = q >> hp.lgTW, qx = q & (hp.TW - 1);
+        const long m = ((long)n_img * p.H + ty0 + qy) * p.W + tx0 + qx;
+#pragma unroll
+        for (int j = 0; j < CT; j++) {
+            const long o = m * p.K + n0 + wn * 64 + j * 16 + cq;
+            half4_t ev = half4_t{0, 0, 0, 0};
+            if (p.mode) ev = *reinterpret_cast<const half4_t *>(p.extra + o);
+            half4_t out;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float v = acc[i][j][e] + (float)bv[j][e];
+                if (p.mode == 1) v += (float)ev[e];
+                v = v > 0.f ? v : v * p.slope;
+                if (p.mode == 2) v += (float)ev[e];
+                out[e] = (_Float16)v;
+            }
+            if (!(dbg & 8)) *reinterpret_cast<half4_t *>(p.y + o) = out;
+        }
+    }
+}
+
 void *g_zero_page = nullptr;
+
+// geometry of the halo kernel for an image size, or false when the shape is not taken (the implicit-GEMM kernel runs it)
+bool halo_geometry(const ConvParams &p, HaloParams &g) {
+    if (p.R != 3 || p.pad != 1 || p.dil != 1 || p.C % 32 || p.K % 128) return false;
+    int tw = p.W < 128 ? p.W : 128;
+    if (tw < 16 || (tw & (tw - 1)) || p.W % tw) return false;
+    const int th = TP / tw;
+    if (p.H % th) return false;
+    g.TW = tw;
+    g.TH = th;
+    g.lgTW = 0;
+    while ((1 << g.lgTW) < tw) g.lgTW++;
+    g.tiles_x = p.W / tw;
+    g.tiles = g.tiles_x * (p.H / th);
+    g.HWp = tw + 2;
+    g.nhalo = (th + 2) * (tw + 2);
+    g.npieces = (g.nhalo + 15) / 16;
+    return g.npieces <= 56;   // 7 pieces per wave and channel block
+}
+
+int launch_halo(const ConvParams &p, const HaloParams &g, hipStream_t st) {
+    const int lds = 2 * g.npieces * SUB + 4 * (128 * 32 * 2) + 8 * SUB;
+    static int attr_lds = 0;
+    if (lds > attr_lds) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_halo<128, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_halo<128, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return PP_ERR_HIP;
+        attr_lds = lds;
+    }
+    const dim3 grid((unsigned)(p.N * g.tiles), (unsigned)(p.K / 128));
+    if (p.dbg) hipLaunchKernelGGL((k_conv3x3_halo<128, true>), grid, dim3(NTHREADS), lds, st, p, g);
+    else hipLaunchKernelGGL((k_conv3x3_halo<128, false>), grid, dim3(NTHREADS), lds, st, p, g);
+    return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
+}
 
 template <int BN>
 int launch(const ConvParams &p, hipStream_t st) {
@@ -251,8 +478,7 @@ PP_API int pp_conv_own_f16(const void *x, const void *w, const void *bias, const
     if (al & 15) return PP_ERR_BAD_ARG;
     const int ho = h + 2 * pad - dilation * (ksize - 1), wo = wd + 2 * pad - dilation * (ksize - 1);
     if (ho <= 0 || wo <= 0) return PP_ERR_BAD_ARG;
-    if (bn == 0) bn = c_out % 256 == 0 ? 256 : (c_out % 128 == 0 ? 128 : 64);
-    if ((bn != 256 && bn != 128 && bn != 64) || c_out % bn) return PP_ERR_UNSUPPORTED;
+    if (bn != 0 && bn != 512 && ((bn != 256 && bn != 128 && bn != 64) || c_out % bn)) return PP_ERR_UNSUPPORTED;
     if (!g_zero_page) {
         if (hipMalloc(&g_zero_page, 256) != hipSuccess || hipMemset(g_zero_page, 0, 256) != hipSuccess) return PP_ERR_HIP;
     }
@@ -267,7 +493,15 @@ PP_API int pp_conv_own_f16(const void *x, const void *w, const void *bias, const
     p.M = (long)n * ho * wo;
     p.mode = extra_mode;
     p.slope = slope;
+    static const int dbg = std::getenv("POSEPAF_CONV_DBG") ? std::atoi(std::getenv("POSEPAF_CONV_DBG")) : 0;
+    p.dbg = dbg;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (bn == 0 || bn == 512) {   // 512: the halo-tile 3x3 kernel (512 pixels x 128 channels per workgroup)
+        HaloParams g;
+        if (halo_geometry(p, g)) return launch_halo(p, g, st);
+        if (bn == 512) return PP_ERR_UNSUPPORTED;
+        bn = c_out % 256 == 0 ? 256 : (c_out % 128 == 0 ? 128 : 64);
+    }
     switch (bn) {
         case 256: return launch<256>(p, st);
         case 128: return launch<128>(p, st);

@@ -26,6 +26,10 @@ USE_PWCONV = False
 # this project's bias / LeakyReLU / residual / post-add functor on the fp32 accumulators).  Per layer shape the tile
 # configurations AND the MIOpen-convolution + separate-epilogue path are timed once, at first (eager) use, and the fastest is kept.
 USE_FUSED_CONV = True
+# Hand-written implicit-GEMM / halo-tile convolution kernels (csrc/posepaf_conv_own.hip) compete in the same per-shape timing:
+# configuration ids >= 100 -> workgroup tile: 256 pixels x 256 / 128 / 64 channels, or 512 = the 3x3 halo-tile kernel
+USE_OWN_CONV = True
+OWN_VARIANTS = {101: 256, 102: 128, 103: 64, 104: 512}
 _conv_choice: dict = {}   # shape key -> tile configuration id, or -1 = MIOpen convolution + k_bias_act pass
 _conv_timing: dict = {}   # shape key -> {"miopen": ms, cfg: ms, ...} measured by the autotune (diagnostics)
 _conv_calls: dict = {}    # shape key -> number of forward() calls since import (diagnostics)
@@ -172,6 +176,10 @@ class FConv(nn.Module):
     def _fused_launch(self, cfg, x, extra, mode, y):
         from . import _lib
         n, c, h, w = x.shape
+        if cfg >= 100:   # hand-written kernels (csrc/posepaf_conv_own.hip): workgroup-tile variant OWN_VARIANTS[cfg]
+            return _lib.load().pp_conv_own_f16(_ptr(x), _ptr(self.weight), _ptr(self.bias), _ptr(extra), _ptr(y), n, h, w, c,
+                                               self.weight.shape[0], self.weight.shape[2], self.padding[0], self.dilation[0], mode,
+                                               LEAK if self.act else 1.0, OWN_VARIANTS[cfg], _stream(x))
         return _lib.load().pp_conv_f16(_ptr(x), _ptr(self.weight), _ptr(self.bias), _ptr(extra), _ptr(y), n, h, w, c,
                                        self.weight.shape[0], self.weight.shape[2], self.padding[0], self.dilation[0], mode,
                                        LEAK if self.act else 1.0, cfg, _stream(x))
@@ -221,7 +229,9 @@ class FConv(nn.Module):
 
         best, best_t = -1, timed(lambda: hip_bias_act_(self.conv_only(x), self.bias, res, self.act, post))
         times = {"miopen": best_t}
-        for cfg in range(L.pp_conv_num_configs()):
+        own = [c_ for c_ in OWN_VARIANTS if USE_OWN_CONV and L.pp_conv_own_supported(x.shape[1], self.weight.shape[0],
+                                                                                     self.weight.shape[2])]
+        for cfg in list(range(L.pp_conv_num_configs())) + own:
             if self._fused_launch(cfg, x, extra, mode, y) != 0:
                 continue
             t = timed(lambda: self._fused_launch(cfg, x, extra, mode, y))

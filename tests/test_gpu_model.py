@@ -262,3 +262,46 @@ def test_own_implicit_gemm_convolution_matches_torch(shape):
             ran += 1
     assert ran >= 10
     assert L.pp_conv_own_supported(72, 64, 3) == 0 and L.pp_conv_own_supported(64, 40, 3) == 0
+
+
+@pytest.mark.parametrize("shape", [
+    # n, c_in, c_out, h, w   (3x3, pad 1): tile 512 pixels = (512 / min(w, 128)) rows x min(w, 128) columns
+    (2, 64, 128, 32, 32),       # one 16 x 32 tile pair per image, 2 channel blocks
+    (1, 256, 256, 16, 64),      # 8 x 64 tiles, two output-channel tiles, 8 channel blocks
+    (1, 96, 128, 128, 128),     # 4 x 128 tiles (the hot layer's geometry), 3 channel blocks, 32 tiles
+    (2, 32, 384, 8, 256),       # 256-wide image: two 4 x 128 tiles per row pair; one channel block (no halo prefetch)
+])
+def test_halo_tile_3x3_convolution_matches_torch(shape):
+    """pp_conv_own_f16 with bn = 512: the 3x3 kernel that keeps the input halo of a 512-pixel tile in LDS and reads the nine
+    taps from it (csrc/posepaf_conv_own.hip k_conv3x3_halo).  Image borders (zero padding), tile borders (halo from the
+    neighbouring tile's pixels), every epilogue variant; asymmetric random operands; tolerance as for the other kernels."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from posepaf import _lib
+    L = _lib.load()
+    n, ci, co, h, w = shape
+    g = torch.Generator(device="cpu").manual_seed(23)
+    x = torch.randn(n, ci, h, w, generator=g).cuda().half().contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(co, ci, 3, 3, generator=g) / (ci * 9) ** 0.5).cuda().half().contiguous(memory_format=torch.channels_last)
+    b = torch.randn(co, generator=g).cuda().half()
+    ex = torch.randn(n, co, h, w, generator=g).cuda().half().contiguous(memory_format=torch.channels_last)
+    conv = F.conv2d(x.float(), wt.float(), b.float(), 1, 1, 1)
+    vp = C.c_void_p
+    stream = vp(torch.cuda.current_stream().cuda_stream)
+    for mode, slope in [(0, 0.01), (1, 0.01), (2, 0.01), (0, 1.0)]:
+        ref = conv + ex.float() if mode == 1 else conv
+        ref = F.leaky_relu(ref, slope) if slope != 1.0 else ref
+        ref = ref + ex.float() if mode == 2 else ref
+        for rep in range(3):     # the same launch repeatedly: a race between the DMA ring and the fragment reads would not repeat
+            y = torch.full((n, co, h, w), float("nan"), dtype=torch.float16, device="cuda").contiguous(memory_format=torch.channels_last)
+            rc = L.pp_conv_own_f16(vp(x.data_ptr()), vp(wt.data_ptr()), vp(b.data_ptr()), vp(ex.data_ptr()) if mode else None,
+                                   vp(y.data_ptr()), n, h, w, ci, co, 3, 1, 1, mode, slope, 512, stream)
+            assert rc == 0, (mode, rc)
+            torch.cuda.synchronize()
+            assert torch.isfinite(y).all(), (shape, mode)
+            err = (y.float() - ref).abs().max().item()
+            assert err <= 2e-3 * max(1.0, ref.abs().max().item()), (shape, mode, slope, rep, err)
+    # shapes the halo kernel does not take are refused (bn = 512) and routed to the implicit-GEMM kernel by bn = 0
+    y = torch.empty((n, co, h, w), dtype=torch.float16, device="cuda").contiguous(memory_format=torch.channels_last)
+    assert L.pp_conv_own_f16(vp(x.data_ptr()), vp(wt.data_ptr()), vp(b.data_ptr()), None, vp(y.data_ptr()), n, h, w, ci, co, 3, 2, 2,
+                             0, 0.01, 512, stream) == -6
