@@ -265,15 +265,18 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     const char *wb = reinterpret_cast<const char *>(p.w);
     const char *zp = reinterpret_cast<const char *>(p.zero);
 
-    // ---- halo DMA sources.  A piece is 16 halo pixels x 64 B, lane-linear in LDS; the swizzle (bit 5 ^= bit 9 of the byte
-    // address inside the halo buffer) is applied on the source side.  Wave w loads pieces w, w+8, ..., w+48 (7 per channel
+    // ---- halo DMA sources.  A piece is 16 halo pixels x 64 B, lane-linear in LDS; the swizzle is applied on the source side.
+    // Halo swizzle: bit 5 ^= bit 8 of the byte address inside the halo buffer, i.e. the two 32-B halves of a pixel swap on
+    // every other group of FOUR pixels.  With it a ds_read_b128 of 16 consecutive pixels x 4 k-groups is bank-conflict free
+    // for EVERY start pixel (taps shift the start by 0 / 1 / 2 pixels and by the halo row length); the weight image's
+    // swizzle (bit 9) would make 14 of 16 start offsets 2-way conflicted.  Wave w loads pieces w, w+8, ..., w+48 (7 per channel
     // block, one per tap 0..6); taps 7 and 8 issue a dummy so that every phase has the same DMA count.
     long hsrc[7];   // byte offset into x for channel block 0, or -1: zero page (outside the image / past the halo)
 #pragma unroll
     for (int t = 0; t < 7; t++) {
         const int piece = t * 8 + wave;
         const int phys = piece * SUB + lane * 16;
-        const int logical = phys ^ (((phys >> 9) & 1) << 5);
+        const int logical = phys ^ (((phys >> 8) & 1) << 5);   // halo swizzle: bit 5 ^= bit 8 (see the fragment reads)
         const int hpix = logical >> 6, chunk = (logical >> 4) & 3;
         const int hy = hpix / hp.HWp, hx = hpix - hy * hp.HWp;
         const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
 #pragma unroll
             for (int i = 0; i < PT; i++) {
                 const int L = hb[i] + tapoff;
-                xf[i] = *reinterpret_cast<const half8_t *>(sh + (L ^ ((L >> 4) & 32)));
+                xf[i] = *reinterpret_cast<const half8_t *>(sh + (L ^ ((L >> 3) & 32)));
             }
         }
         // retire this wave's DMA up to the weight slice of phase ph+1 (and every halo piece issued two phases ago or earlier):
