@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Merge two rocprofv3 --pmc passes (FETCH_SIZE alone, WRITE_SIZE alone) of `bench.py --postproc-only --batch B` into
-profiles/r01_pmc_traffic.json: HBM bytes per launch of K_A / K_B / K_C.
+profiles/r02_pmc_traffic.json: HBM bytes per launch of K_A (k_heat_peaks) and K_B (k_limb_connect, which includes the person
+assembly since round 2).
 
     python tools/pmc_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <B>
 
@@ -15,7 +16,7 @@ import sys
 
 fdir, wdir, B = sys.argv[1], sys.argv[2], int(sys.argv[3])
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = {"k_heat_peaks": "k_heat_peaks", "k_limb_connect": "k_limb_connect<", "k_assemble": "k_assemble("}
+KERNELS = {"k_heat_peaks": "k_heat_peaks", "k_limb_connect": "k_limb_connect<"}
 
 
 def per_launch(d, counter):
@@ -32,8 +33,12 @@ def per_launch(d, counter):
 
 
 fetch, write = per_launch(fdir, "FETCH_SIZE"), per_launch(wdir, "WRITE_SIZE")
-out_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-out = json.load(open(out_path)) if os.path.exists(out_path) else {}
+out_path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+out = json.load(open(out_path)) if os.path.exists(out_path) else {
+    "_note": "HBM traffic per launch from rocprofv3 --pmc (separate passes: FETCH_SIZE alone, WRITE_SIZE alone) of `bench.py "
+             "--postproc-only --batch B`, merged by tools/pmc_traffic.py. rocprofv3 reports KiB. On gfx950 FETCH_SIZE counts exactly "
+             "half of the bytes of a wide coalesced (16 B/lane) streaming read (MI355X_MICROARCH.md, section HBM), so traffic = "
+             "(2*FETCH_SIZE + WRITE_SIZE)*1024."}
 out.setdefault("_raw_kib_by_batch", {})[f"batch{B}"] = {k: {"FETCH_SIZE": fetch[k], "WRITE_SIZE": write[k]} for k in fetch}
 for k in fetch:
     out.setdefault(k, {})[f"batch{B}"] = (2 * fetch[k] + write[k]) * 1024
