@@ -92,11 +92,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "evaluate.py needs MI355X GPUs"
+    backend = os.environ.get("POSEPAF_DIST_BACKEND", "nccl")   # "gloo": rehearsal of the N > 1 control flow on fewer GPUs
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
     torch.backends.cudnn.benchmark = True
 
     from config.config import GetConfig, TrainingOpt
@@ -226,7 +231,8 @@ def main():
     dt_local = time.perf_counter() - t0
 
     if world > 1:
-        merged = pdist.gather_records(local_recs[:S * RECORD_BYTES], len(mine))
+        shard = local_recs[:S * RECORD_BYTES]
+        merged = pdist.gather_records(shard if backend == "nccl" else shard.cpu(), len(mine))
     else:
         from posepaf.api import records_to_numpy
         merged = records_to_numpy(local_recs[:len(mine) * RECORD_BYTES])

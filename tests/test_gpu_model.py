@@ -306,3 +306,52 @@ def test_halo_tile_3x3_convolution_matches_torch(shape):
     y = torch.empty((n, co, h, w), dtype=torch.float16, device="cuda").contiguous(memory_format=torch.channels_last)
     assert L.pp_conv_own_f16(vp(x.data_ptr()), vp(wt.data_ptr()), vp(b.data_ptr()), None, vp(y.data_ptr()), n, h, w, ci, co, 3, 2, 2,
                              0, 0.01, 512, stream) == -6
+
+
+def test_evaluate_two_ranks_on_one_gpu_gloo_rehearsal(tmp_path):
+    """BASELINE configs[3]'s control flow on hardware: `evaluate.py --gpus 2` launches its own two ranks (one GPU shared, record
+    exchange over gloo: POSEPAF_DIST_BACKEND=gloo), images sharded i mod 2, records gathered and re-interleaved into image
+    order; the dump must equal the single-process run's."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import PKG
+    outs = []
+    for gpus in (1, 2):
+        dump = tmp_path / f"res{gpus}.json"
+        env = dict(os.environ, POSEPAF_DIST_BACKEND="gloo")
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+            env.pop(k, None)
+        r = subprocess.run([sys.executable, os.path.join(PKG, "evaluate.py"), "--gpus", str(gpus), "--run_refactor", "--run_cpp",
+                            "--synthetic", "5", "--sizes", "256x256", "--batch", "2", "--people", "3", "--dump_name", str(dump)],
+                           capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        summary = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert summary["world"] == gpus and summary["images"] == 5 and summary["status_or"] == 0
+        outs.append(json.load(open(dump)))
+    # the forward of an image depends (in its last fp16 bits) on the batch it runs in, so people are compared with a tolerance:
+    # same images, same number of people per image in the same order, joints within one feature-map cell, scores within 1e-2
+    assert len(outs[0]) >= 10 and len(outs[0]) == len(outs[1])
+    for a_, b_ in zip(outs[0], outs[1]):
+        assert a_["image_id"] == b_["image_id"]
+        ka, kb = np.array(a_["keypoints"]).reshape(17, 3), np.array(b_["keypoints"]).reshape(17, 3)
+        assert np.array_equal(ka[:, 2], kb[:, 2]) and np.abs(ka[:, :2] - kb[:, :2]).max() <= 4
+        assert abs(a_["score"] - b_["score"]) < 1e-2
+
+
+def test_util_keypoint_heatmap_nms_routes_to_the_hip_kernel():
+    """utils.util.keypoint_heatmap_nms on a device tensor == the torch expression of utils/util.py:177-185 (reflect pad + 3x3
+    max pool, >= thre), computed through K_A's 3x3 mode."""
+    import torch.nn.functional as F
+    from utils import util
+    g = torch.Generator(device="cpu").manual_seed(3)
+    heat = (torch.rand(1, 18, 24, 40, generator=g) ** 30).cuda()     # ~70 pixels per channel above the threshold
+    heat[0, :, 0, 0] = 0.9
+    heat[0, :, 23, 39] = 0.8
+    heat[0, 3, 10, 10] = heat[0, 3, 10, 11] = 0.95           # plateau: both kept (>= comparison)
+    assert util._hip_keypoint_nms(heat, 0.1) is not None      # the HIP path takes this map (no silent torch fallback)
+    got = util.keypoint_heatmap_nms(heat, kernel=3, thre=0.1)
+    hmax = F.max_pool2d(F.pad(heat, (1, 1, 1, 1), mode="reflect"), 3, stride=1)
+    want = heat * ((hmax == heat).float() * (heat >= 0.1).float())
+    assert torch.equal(got, want) and (got != 0).sum() > 300
