@@ -22,6 +22,7 @@
 
 #include <cstdint>
 #include <cstdlib>
+#include <type_traits>
 
 #include "../../include/posepaf.h"
 
@@ -246,22 +247,28 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     constexpr int PM = TP / WM;          // 128 pixels per wave
     constexpr int PT = PM / 16;          // 8
     constexpr int CT = 4;
-    constexpr int WB = BN * 32 * 2;      // weight slice of one phase
-    constexpr int NL = 2;                // DMA instructions per wave and phase: one halo piece (or a dummy), one weight sub-tile
+    constexpr int WB = BN * 32 * 2;      // weight slice of one phase: 8 sub-tiles, one per wave
+    constexpr int NW = 6;                // weight ring: the slice of phase ph + 4 is issued while phase ph is multiplied
+    constexpr int HP = 56;               // halo pieces per buffer: 7 per wave (pieces past the halo are zero-page reads)
     static_assert(BN == 128, "one weight sub-tile per wave and phase");
     extern __shared__ __align__(16) unsigned char smem[];
-    const int halo_bytes = hp.npieces * SUB;
-    unsigned char *s_halo = smem;                               // [2][npieces * 1 KiB]
-    unsigned char *s_w = smem + 2 * halo_bytes;                 // [4][WB]
-    unsigned char *s_dummy = s_w + 4 * WB;                      // [8][1 KiB] landing zone of the padding DMAs
+    constexpr int halo_bytes = HP * SUB;
+    unsigned char *s_halo = smem;                               // [2][56 KiB]
+    unsigned char *s_w = smem + 2 * halo_bytes;                 // [NW][WB]
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int n_img = blockIdx.x / hp.tiles, tile = blockIdx.x - n_img * hp.tiles;
+    // 1-D grid.  Workgroups b and b + 8 share an XCD (and its L2) under the round-robin placement: the channel tiles of ONE
+    // pixel tile are 8 ids apart, so the second one finds the halo its sibling just fetched in L2 (speed only, never needed).
+    const int nct = p.K / BN;
+    const int grp8 = blockIdx.x / (8 * nct), in8 = blockIdx.x - grp8 * (8 * nct);
+    const int ptile = grp8 * 8 + (in8 & 7), ctile = in8 >> 3;
+    if (ptile >= (int)(p.N * hp.tiles)) return;   // padding of the last group of eight
+    const int n_img = ptile / hp.tiles, tile = ptile - n_img * hp.tiles;
     const int ty0 = (tile / hp.tiles_x) * hp.TH, tx0 = (tile - (tile / hp.tiles_x) * hp.tiles_x) * hp.TW;
-    const int n0 = blockIdx.y * BN;
-    const char *xb = reinterpret_cast<const char *>(p.x);
+    const int n0 = ctile * BN;
+    const char *xb = reinterpret_cast<const char *>(p.x) + (long)n_img * p.H * p.W * p.C * 2;   // this image
     const char *wb = reinterpret_cast<const char *>(p.w);
     const char *zp = reinterpret_cast<const char *>(p.zero);
 
@@ -269,46 +276,41 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     // Halo swizzle: bit 5 ^= bit 8 of the byte address inside the halo buffer, i.e. the two 32-B halves of a pixel swap on
     // every other group of FOUR pixels.  With it a ds_read_b128 of 16 consecutive pixels x 4 k-groups is bank-conflict free
     // for EVERY start pixel (taps shift the start by 0 / 1 / 2 pixels and by the halo row length); the weight image's
-    // swizzle (bit 9) would make 14 of 16 start offsets 2-way conflicted.  Wave w loads pieces w, w+8, ..., w+48 (7 per channel
-    // block, one per tap 0..6); taps 7 and 8 issue a dummy so that every phase has the same DMA count.
-    long hsrc[7];   // byte offset into x for channel block 0, or -1: zero page (outside the image / past the halo)
+    // swizzle (bit 9) would make 14 of 16 start offsets 2-way conflicted.
+    // Wave w loads pieces w, w + 8, ..., w + 48 of every channel block: two at tap 0, one at taps 1..5 (see the DMA schedule).
+    int hsrc[7];   // byte offset inside the image for channel block 0, or -1: zero page (outside the image / past the halo)
 #pragma unroll
     for (int t = 0; t < 7; t++) {
         const int piece = t * 8 + wave;
         const int phys = piece * SUB + lane * 16;
-        const int logical = phys ^ (((phys >> 8) & 1) << 5);   // halo swizzle: bit 5 ^= bit 8 (see the fragment reads)
+        const int logical = phys ^ (((phys >> 8) & 1) << 5);
         const int hpix = logical >> 6, chunk = (logical >> 4) & 3;
         const int hy = hpix / hp.HWp, hx = hpix - hy * hp.HWp;
         const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
-        const bool ok = piece < hp.npieces && hpix < hp.nhalo && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        hsrc[t] = ok ? ((((long)n_img * p.H + iy) * p.W + ix) * p.C * 2 + chunk * 16) : -1;
+        const bool ok = hpix < hp.nhalo && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        hsrc[t] = ok ? ((iy * p.W + ix) * p.C * 2 + chunk * 16) : -1;
     }
     // weight sub-tile of this wave: 16 output channels x 32 halves per phase
     const int b = lane * 16;
     const int bs = b ^ (((b >> 9) & 1) << 5);
-    const long wrow = 9L * p.C * 2;
-    const long woff = (long)(n0 + wave * 16 + (bs >> 6)) * wrow + (bs & 63);
+    const long woff = (long)(n0 + wave * 16 + (bs >> 6)) * (9L * p.C * 2) + (bs & 63);
 
     const int ncb = p.C / 32;
     const int np = ncb * 9;
     int st_cb = 0, st_tap = 0;   // (channel block, tap) of the NEXT weight slice to stage
-    auto stage_w = [&](int slot) {
-        lds_dma16(wb + woff + ((long)st_tap * p.C + (long)st_cb * 32) * 2, s_w + slot * WB + wave * SUB);
+    int st_slot = 0;
+    auto stage_w = [&]() {
+        lds_dma16(wb + woff + ((long)st_tap * p.C + (long)st_cb * 32) * 2, s_w + st_slot * WB + wave * SUB);
+        if (++st_slot == NW) st_slot = 0;
         if (++st_tap == 9) {
             st_tap = 0;
             ++st_cb;
         }
     };
-    auto stage_halo = [&](int t, int cb, int buf) {   // piece t*8+wave of channel block cb into halo buffer buf; t >= 7: dummy
-        if (t < 7 && t * 8 + wave < hp.npieces) {
-            long off = -1;
-#pragma unroll
-            for (int q = 0; q < 7; q++) off = t == q ? hsrc[q] : off;
-            const uintptr_t src = off >= 0 ? reinterpret_cast<uintptr_t>(xb) + (uintptr_t)(off + (long)cb * 64) : reinterpret_cast<uintptr_t>(zp);
-            lds_dma16(reinterpret_cast<const void *>(src), s_halo + buf * halo_bytes + (t * 8 + wave) * SUB);
-        } else {
-            lds_dma16(zp, s_dummy + wave * SUB);
-        }
+    auto stage_halo = [&](int t, int cb, int buf) {   // piece t * 8 + wave (t compile-time 0..6) of channel block cb
+        const uintptr_t src = hsrc[t] >= 0 ? reinterpret_cast<uintptr_t>(xb) + (uintptr_t)((long)hsrc[t] + (long)cb * 64)
+                                           : reinterpret_cast<uintptr_t>(zp);
+        lds_dma16(reinterpret_cast<const void *>(src), s_halo + buf * halo_bytes + (t * 8 + wave) * SUB);
     };
 
     float4_t acc[PT][CT];
@@ -318,68 +320,97 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
         for (int j = 0; j < CT; j++) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
 
     // fragment addresses.  Weights: sub-tile image as above.  Pixels: lane reads 16 B (k group g) of halo pixel
-    // (qy + r) * HWp + qx + s for its output pixel q; hb[i] is the tap-(0,0) byte address, the tap adds a uniform offset.
+    // (qy + r) * HWp + qx + s for its output pixel q; pixel tile i starts at tile pixel wm * 128 + 16 i (a multiple of 16 <= TW), so
+    // its halo offset relative to tile 0 is wave-uniform: ONE vector register holds the lane part.
     const int wfrag = (lane & 15) * 64 + (((lane >> 4) * 16) ^ (((lane & 15) >> 3) << 5));
-    int hb[PT];
-#pragma unroll
-    for (int i = 0; i < PT; i++) {
-        const int q = wm * PM + i * 16 + (lane & 15);
-        const int qy = q >> hp.lgTW, qx = q & (hp.TW - 1);
-        hb[i] = (qy * hp.HWp + qx) * 64 + (lane >> 4) * 16;
-    }
+    const int hb0 = (((wm * PM) >> hp.lgTW) * hp.HWp + ((wm * PM) & (hp.TW - 1)) + (lane & 15)) * 64 + (lane >> 4) * 16;
+    auto xaddr_from = [&](int base, int i, int tapoff_) {
+        const int L = base + tapoff_ + ((((i * 16) >> hp.lgTW) * hp.HWp + ((i * 16) & (hp.TW - 1))) * 64);
+        return L ^ ((L >> 3) & 32);
+    };
+    auto xaddr = [&](int i, int tapoff_) { return xaddr_from(hb0, i, tapoff_); };
 
-    // ---- prologue: halo of channel block 0 (7 pieces per wave) and the weights of phases 0..2; everything landed
+    // ---- prologue: halo of channel block 0 (7 pieces per wave) and the weights of phases 0..3; everything landed
+#pragma unroll
     for (int t = 0; t < 7; t++) stage_halo(t, 0, 0);
-    for (int q = 0; q < 3 && q < np; q++) stage_w(q);
+    for (int q = 0; q < 4 && q < np; q++) stage_w();
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    const int grp = wave >> 2;
-    if (grp == 1) __builtin_amdgcn_s_barrier();
-    int cb = 0, tap = 0;
-    for (int ph = 0; ph < np; ph++) {
-        // LOAD section: DMA of this phase (halo piece of the NEXT channel block first, then the weight slice of phase ph+3)
+    half8_t wf[CT], xf[PT];
+#pragma unroll
+    for (int j = 0; j < CT; j++) wf[j] = *reinterpret_cast<const half8_t *>(s_w + (wn * 4 + j) * SUB + wfrag);
+#pragma unroll
+    for (int i = 0; i < PT; i++) xf[i] = *reinterpret_cast<const half8_t *>(s_halo + xaddr(i, 0));
+
+    // ---- main loop: channel blocks x 9 taps (unrolled: the DMA count of a tap is a compile-time constant).
+    // In-place fragment refill: the registers hold the fragments of phase ph when its MFMAs start; as soon as the four MFMAs
+    // that use a pixel fragment (and, in the last pixel tile, a weight fragment) have been issued, that register is reloaded
+    // with the SAME fragment of phase ph + 1: one ds_read_b128 every four MFMAs, no second register set, no LDS burst ahead of
+    // the matrix work.
+    // DMA schedule of a wave, per tap: one weight sub-tile (phase ph + 4, ring slot of phase ph - 2), plus, while a next channel
+    // block exists, its halo pieces: two at tap 0, one at taps 1..5, none at 6..8 -- so every halo piece is at least THREE phases
+    // old when tap 8 starts to read the next block's fragments.  After the MFMAs the wave waits until only the DMA of THIS and
+    // the PREVIOUS phase is in flight (counted vmcnt, the count is the schedule's), then the barrier publishes what landed:
+    // the weight slice of phase ph + 2, read one phase later.  No dummy DMA anywhere: a CU's DMA path moves ~1 KiB per 60-85
+    // cycles whatever the bytes are worth, and it is this path, not the matrix pipe, that bounds the implicit-GEMM form.
+    int ph = 0;
+    auto phase = [&](auto TAP, auto HALO, int cb) {
+        constexpr int tap = decltype(TAP)::value;
+        constexpr bool halo = decltype(HALO)::value;     // a next channel block exists: its halo streams in
+        constexpr int ntap = tap == 8 ? 0 : tap + 1;
+        constexpr int c_this = 1 + (halo ? (tap == 0 ? 2 : (tap <= 5 ? 1 : 0)) : 0);
+        constexpr int ptap = tap == 0 ? 8 : tap - 1;
+        // DMA issued by the previous phase: tap - 1 of this block, or tap 8 of the previous block (weights only)
+        constexpr int c_prev = 1 + ((halo && tap != 0) ? (ptap == 0 ? 2 : (ptap <= 5 ? 1 : 0)) : 0);
         if (!(dbg & 1)) {
-            if (cb + 1 < ncb) stage_halo(tap, cb + 1, (cb + 1) & 1);
-            else lds_dma16(zp, s_dummy + wave * SUB);
-            if (ph + 3 < np) stage_w((ph + 3) & 3);
-            else lds_dma16(zp, s_dummy + wave * SUB);
-        }
-        const int r = tap / 3, sx = tap - r * 3;
-        const int tapoff = (r * hp.HWp + sx) * 64;
-        const unsigned char *sh = s_halo + (cb & 1) * halo_bytes;
-        const unsigned char *sw = s_w + (ph & 3) * WB;
-        half8_t wf[CT], xf[PT];
-        if (!(dbg & 4) || ph == 0) {
-#pragma unroll
-            for (int j = 0; j < CT; j++) wf[j] = *reinterpret_cast<const half8_t *>(sw + (wn * 4 + j) * SUB + wfrag);
-#pragma unroll
-            for (int i = 0; i < PT; i++) {
-                const int L = hb[i] + tapoff;
-                xf[i] = *reinterpret_cast<const half8_t *>(sh + (L ^ ((L >> 3) & 32)));
+            if (halo) {
+                if (tap == 0) {
+                    stage_halo(0, cb + 1, (cb + 1) & 1);
+                    stage_halo(6, cb + 1, (cb + 1) & 1);
+                } else if (tap <= 5) {
+                    stage_halo(tap, cb + 1, (cb + 1) & 1);
+                }
             }
+            if (ph + 4 < np) stage_w();
         }
-        // retire this wave's DMA up to the weight slice of phase ph+1 (and every halo piece issued two phases ago or earlier):
-        // the two newest phases' instructions (2 x NL) may stay in flight
-        wait_vmcnt<2 * NL>();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        // MULTIPLY section
-        if (!(dbg & 2)) {
-            __builtin_amdgcn_s_setprio(1);
+        const int ncb_ = tap == 8 ? cb + 1 : cb;
+        const bool more = ph + 1 < np;
+        constexpr int nr = ntap / 3, nsx = ntap - nr * 3;
+        const int ntapoff = (nr * hp.HWp + nsx) * 64;
+        const unsigned char *nsh = s_halo + (ncb_ & 1) * halo_bytes;
+        const unsigned char *nsw = s_w + ((ph + 1) % NW) * WB;
+        int base = hb0;
+        asm volatile("" : "+v"(base));   // keeps the 72 per-tap fragment addresses from being hoisted out of the block loop
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int i = 0; i < PT; i++)
+        for (int i = 0; i < PT; i++) {
 #pragma unroll
-                for (int j = 0; j < CT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
+            for (int j = 0; j < CT; j++) {
+                if (!(dbg & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+                if (i == PT - 1 && more && !(dbg & 4))   // last use of weight fragment j in this phase
+                    wf[j] = *reinterpret_cast<const half8_t *>(nsw + (wn * 4 + j) * SUB + wfrag);
+            }
+            if (more && !(dbg & 4)) xf[i] = *reinterpret_cast<const half8_t *>(nsh + xaddr_from(base, i, ntapoff));
         }
+        __builtin_amdgcn_s_setprio(0);
+        if (ph + 4 < np) wait_vmcnt<c_this + c_prev>();
+        else wait_vmcnt<0>();     // the last phases issue no weights: drain (three phases, negligible)
         __builtin_amdgcn_s_barrier();
-        if (++tap == 9) {
-            tap = 0;
-            ++cb;
-        }
-    }
-    if (grp == 0) __builtin_amdgcn_s_barrier();
-    wait_vmcnt<0>();   // the trailing dummies
+        ++ph;
+    };
+    auto block = [&](auto HALO, int cb) {
+        phase(std::integral_constant<int, 0>{}, HALO, cb);
+        phase(std::integral_constant<int, 1>{}, HALO, cb);
+        phase(std::integral_constant<int, 2>{}, HALO, cb);
+        phase(std::integral_constant<int, 3>{}, HALO, cb);
+        phase(std::integral_constant<int, 4>{}, HALO, cb);
+        phase(std::integral_constant<int, 5>{}, HALO, cb);
+        phase(std::integral_constant<int, 6>{}, HALO, cb);
+        phase(std::integral_constant<int, 7>{}, HALO, cb);
+        phase(std::integral_constant<int, 8>{}, HALO, cb);
+    };
+    for (int cb = 0; cb + 1 < ncb; cb++) block(std::true_type{}, cb);
+    block(std::false_type{}, ncb - 1);
 
     // ---- epilogue from registers
     const int cq = (lane >> 4) * 4;
@@ -771,7 +802,7 @@ bool halo_geometry(const ConvParams &p, HaloParams &g) {
     g.HWp = tw + 2;
     g.nhalo = (th + 2) * (tw + 2);
     g.npieces = (g.nhalo + 15) / 16;
-    return g.npieces <= 56;   // 7 pieces per wave and channel block
+    return g.npieces <= 56;   // at most 7 or 8 pieces per wave and channel block, all three launch forms
 }
 
 int launch_halo16(const ConvParams &p, const HaloParams &g, hipStream_t st) {
@@ -804,7 +835,7 @@ int launch_halo4(const ConvParams &p, const HaloParams &g, hipStream_t st) {
 }
 
 int launch_halo(const ConvParams &p, const HaloParams &g, hipStream_t st) {
-    const int lds = 2 * g.npieces * SUB + 4 * (128 * 32 * 2) + 8 * SUB;
+    const int lds = 2 * 56 * SUB + 6 * (128 * 32 * 2);   // two halo buffers of 56 pieces, weight ring of 6 slices
     static int attr_lds = 0;
     if (lds > attr_lds) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_halo<128, false>),
@@ -814,7 +845,8 @@ int launch_halo(const ConvParams &p, const HaloParams &g, hipStream_t st) {
             return PP_ERR_HIP;
         attr_lds = lds;
     }
-    const dim3 grid((unsigned)(p.N * g.tiles), (unsigned)(p.K / 128));
+    const unsigned ptiles = (unsigned)(p.N * g.tiles);
+    const dim3 grid(((ptiles + 7) / 8) * 8 * (unsigned)(p.K / 128));
     if (p.dbg) hipLaunchKernelGGL((k_conv3x3_halo<128, true>), grid, dim3(NTHREADS), lds, st, p, g);
     else hipLaunchKernelGGL((k_conv3x3_halo<128, false>), grid, dim3(NTHREADS), lds, st, p, g);
     return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
