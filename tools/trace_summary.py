@@ -18,8 +18,8 @@ with open(f) as fh:
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
 hp = [i for i, r in enumerate(rows) if "k_heat_peaks" in r[2]]
-# bench.py: warmup+steps launches of K_A inside steps, then 1 + 20 more from pp_time_kernels
-n_step_launches = len(hp) - 21
+# bench.py: warmup+steps launches of K_A inside steps, then 1 + 20 (K_A alone) + 20 (the chain) more from pp_time_kernels
+n_step_launches = len(hp) - 41
 a, b = hp[n_step_launches - 2], hp[n_step_launches - 1]
 seg = rows[a + 1:b + 1]
 agg = collections.defaultdict(lambda: [0, 0])
