@@ -66,3 +66,6 @@ def default_model_cfg():
     """`model` dict of utils/config_reader.py (utils/config [[1]] section), typed."""
     return {"boxsize": BOXSIZE, "padValue": PAD_VALUE, "np": "12", "stride": STRIDE,
             "max_downsample": MAX_DOWNSAMPLE, "part_str": list(PART_STR_INI)}
+
+# config/config.py:154: the limb types the original demo drawing renders
+DRAW_LIST = [0] + list(range(5, 21)) + [29]

@@ -357,3 +357,26 @@ def test_util_keypoint_heatmap_nms_routes_to_the_hip_kernel():
     hmax = F.max_pool2d(F.pad(heat, (1, 1, 1, 1), mode="reflect"), 3, stride=1)
     want = heat * ((hmax == heat).float() * (heat >= 0.1).float())
     assert torch.equal(got, want) and (got != 0).sum() > 300
+
+
+@pytest.mark.parametrize("flags", [["--run_refactor", "--run_cpp"], ["--run_refactor"], []])
+def test_demo_image_script_draws_the_injected_people(tmp_path, flags):
+    """improved-body-parts_amd/demo_image.py (reference demo_image.py:80-321, same flags): one image through the three branches
+    (pafprocess rules, Python rules, original path), rendering by utils/draw.py.  Offline the people come from a synthetic
+    scene added to the network output; the canvas must differ from the input exactly where skeletons were drawn."""
+    import os
+    import subprocess
+    import sys
+    from conftest import PKG
+    img = np.random.default_rng(5).integers(0, 256, (256, 256, 3), dtype=np.uint8)
+    src, dst = tmp_path / "in.npy", tmp_path / "out.npy"
+    np.save(src, img)
+    r = subprocess.run([sys.executable, os.path.join(PKG, "demo_image.py"), "--image", str(src), "--output", str(dst), "--synthetic", "3",
+                        *flags], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    n_people = int(r.stdout.strip().splitlines()[-1].split(",")[1].split()[0])
+    assert n_people >= 2, r.stdout
+    out = np.load(dst)
+    assert out.shape == img.shape and out.dtype == np.uint8
+    changed = (out != img).any(axis=2)
+    assert 500 < changed.sum() < 0.5 * changed.size          # skeletons drawn, most of the image untouched
