@@ -1316,6 +1316,8 @@ __device__ __forceinline__ void assemble_pass(AsmState &S, const AsmWaveLds &A, 
     }
     if (stamps) S.class_cycles += (long long)clock64() - tc0;
     // ---- 3. in connection order: maximal runs of independent connections in one step, the others one by one
+    // (a run's found-1 updates cannot be hoisted in front of an earlier flagged connection: its merge may ADD two ids into an
+    // id that a later connection of the pass holds, and that connection must then see it)
     int pos = 0;
     while (pos < mc) {
         const unsigned long long rest = confm >> pos;
@@ -1323,8 +1325,12 @@ __device__ __forceinline__ void assemble_pass(AsmState &S, const AsmWaveLds &A, 
         next = next < mc ? next : mc;
         if (next > pos) {
 #pragma unroll
-            for (int b = 0; b < NB; b++)
-                if (myk[b] >= pos && myk[b] < next) apply_found1(K[b], A, b * 64 + lane, part2, f_id2[b], f_cs[b], f_cl[b], f_ps2[b]);
+            for (int b = 0; b < NB; b++) {
+                const bool mine = myk[b] >= pos && myk[b] < next;
+                if (__ballot(mine)) {   // wave-uniform: a bank without work in this run skips the update code instead of masking it
+                    if (mine) apply_found1(K[b], A, b * 64 + lane, part2, f_id2[b], f_cs[b], f_cl[b], f_ps2[b]);
+                }
+            }
             const bool born = isnew && lane >= pos && lane < next;
             const unsigned long long mnew = __ballot(born);
             if (mnew) {  // :257-273 new skeletons, slots in connection order
@@ -1368,7 +1374,9 @@ __device__ __forceinline__ void assemble_pass(AsmState &S, const AsmWaveLds &A, 
                 const float u_ps2 = rlf(ps2, next);
 #pragma unroll
                 for (int b = 0; b < NB; b++)
-                    if ((idx1 >> 6) == b && (idx1 & 63) == lane) apply_found1(K[b], A, idx1, part2, u_id2, u_cs, u_cl, u_ps2);
+                    if ((idx1 >> 6) == b) {   // wave-uniform: the other banks' copies of the update are skipped, not masked
+                        if ((idx1 & 63) == lane) apply_found1(K[b], A, idx1, part2, u_id2, u_cs, u_cl, u_ps2);
+                    }
             } else if (num_found == 2) {  // :182-256, one part per lane; LDS is current (write-through)
                 wave_lds_sync();
                 const bool isp = lane < PP_NUM_PART;
