@@ -54,6 +54,53 @@ __device__ __forceinline__ void lds_dma16(const void *gsrc, unsigned char *lds_w
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
+// Epilogue from registers with 16-byte stores.  After the MFMAs a lane holds, per (pixel tile i, channel tile j), four
+// consecutive channels (4 * (lane >> 4) ...) of pixel lane & 15: 8 bytes.  A row-per-lane epilogue of 8-byte stores is
+// store-ISSUE bound (32 of them per lane here).  Lanes l and l ^ 16 hold ADJACENT channel quads of the same pixel, so channel
+// tiles are handled in pairs: the even-quad lane takes both quads of tile j, the odd-quad lane both quads of tile j + 1 (one
+// cross-lane exchange of four accumulators each way), and every lane then finishes eight consecutive channels -- bias,
+// residual, LeakyReLU, post add in fp32, one 16-byte load of `extra`, one 16-byte store: half the memory instructions.
+// pixel_of(i): flat output pixel index of this lane in pixel tile i, or -1 (outside the tensor).
+template <int PT, int CT, typename PixelOf>
+__device__ __forceinline__ void epilogue_store(const float4_t (&acc)[PT][CT], const ConvParams &p, int lane, int nbase,
+                                               PixelOf pixel_of, bool do_store) {
+    static_assert(CT % 2 == 0, "channel tiles are finished in pairs");
+    const int g = lane >> 4, odd = g & 1, cbase = (g & ~1) * 4;
+#pragma unroll
+    for (int jp = 0; jp < CT; jp += 2) {
+        const int co = nbase + (jp + odd) * 16 + cbase;
+        const half8_t bv = *reinterpret_cast<const half8_t *>(p.bias + co);
+#pragma unroll
+        for (int i = 0; i < PT; i++) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float keep = odd ? acc[i][jp + 1][e] : acc[i][jp][e];
+                const float send = odd ? acc[i][jp][e] : acc[i][jp + 1][e];
+                const float recv = __shfl_xor(send, 16);
+                v[e] = odd ? recv : keep;       // the lower quad comes from the even-quad lane
+                v[4 + e] = odd ? keep : recv;
+            }
+            const long m = pixel_of(i);
+            if (m >= 0) {
+                const long o = m * p.K + co;
+                half8_t ev = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+                if (p.mode) ev = *reinterpret_cast<const half8_t *>(p.extra + o);
+                half8_t out;
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    float t = v[e] + (float)bv[e];
+                    if (p.mode == 1) t += (float)ev[e];
+                    t = t > 0.f ? t : t * p.slope;
+                    if (p.mode == 2) t += (float)ev[e];
+                    out[e] = (_Float16)t;
+                }
+                if (do_store) *reinterpret_cast<half8_t *>(p.y + o) = out;
+            }
+        }
+    }
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -191,33 +238,11 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_igemm(const ConvParams p) {
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();
 
-    // ---- epilogue from registers: lane holds, per (pixel tile, channel tile), 4 consecutive channels of one pixel
-    const int cq = (lane >> 4) * 4;
-    half4_t bv[CT];
-#pragma unroll
-    for (int j = 0; j < CT; j++) bv[j] = *reinterpret_cast<const half4_t *>(p.bias + n0 + wn * 64 + j * 16 + cq);
-#pragma unroll
-    for (int i = 0; i < PT; i++) {
+    // ---- epilogue from registers (16-byte stores: epilogue_store)
+    epilogue_store<PT, CT>(acc, p, lane, n0 + wn * 64, [&](int i) -> long {
         const long m = m0 + wm * PM + i * 16 + (lane & 15);
-        if (m < p.M) {
-#pragma unroll
-            for (int j = 0; j < CT; j++) {
-                const long o = m * p.K + n0 + wn * 64 + j * 16 + cq;
-                half4_t ev = half4_t{0, 0, 0, 0};
-                if (p.mode) ev = *reinterpret_cast<const half4_t *>(p.extra + o);
-                half4_t out;
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    float v = acc[i][j][e] + (float)bv[j][e];
-                    if (p.mode == 1) v += (float)ev[e];
-                    v = v > 0.f ? v : v * p.slope;
-                    if (p.mode == 2) v += (float)ev[e];
-                    out[e] = (_Float16)v;
-                }
-                *reinterpret_cast<half4_t *>(p.y + o) = out;
-            }
-        }
-    }
+        return m < p.M ? m : -1;
+    }, true);
 }
 
 // ------------------------------------------------------------------------------------------------ 3x3, halo tile in LDS
@@ -261,10 +286,13 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     const int wm = wave / WN, wn = wave % WN;
     // 1-D grid.  Workgroups b and b + 8 share an XCD (and its L2) under the round-robin placement: the channel tiles of ONE
     // pixel tile are 8 ids apart, so the second one finds the halo its sibling just fetched in L2 (speed only, never needed).
+    // Each XCD (ids congruent mod 8) walks a CONTIGUOUS range of pixel tiles, all channel tiles of a pixel tile back to back:
+    // the sibling channel tile and the vertically adjacent pixel tile (two shared halo rows) find their input in that L2.
     const int nct = p.K / BN;
-    const int grp8 = blockIdx.x / (8 * nct), in8 = blockIdx.x - grp8 * (8 * nct);
-    const int ptile = grp8 * 8 + (in8 & 7), ctile = in8 >> 3;
-    if (ptile >= (int)(p.N * hp.tiles)) return;   // padding of the last group of eight
+    const int ptiles = p.N * hp.tiles, per_xcd = (ptiles + 7) >> 3;
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int ptile = xcd * per_xcd + q / nct, ctile = q - (q / nct) * nct;
+    if (q / nct >= per_xcd || ptile >= ptiles) return;   // padding of the last range
     const int n_img = ptile / hp.tiles, tile = ptile - n_img * hp.tiles;
     const int ty0 = (tile / hp.tiles_x) * hp.TH, tx0 = (tile - (tile / hp.tiles_x) * hp.tiles_x) * hp.TW;
     const int n0 = ctile * BN;
@@ -412,33 +440,12 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     for (int cb = 0; cb + 1 < ncb; cb++) block(std::true_type{}, cb);
     block(std::false_type{}, ncb - 1);
 
-    // ---- epilogue from registers
-    const int cq = (lane >> 4) * 4;
-    half4_t bv[CT];
-#pragma unroll
-    for (int j = 0; j < CT; j++) bv[j] = *reinterpret_cast<const half4_t *>(p.bias + n0 + wn * 64 + j * 16 + cq);
-#pragma unroll
-    for (int i = 0; i < PT; i++) {
+    // ---- epilogue from registers (16-byte stores: epilogue_store)
+    epilogue_store<PT, CT>(acc, p, lane, n0 + wn * 64, [&](int i) -> long {
         const int q = wm * PM + i * 16 + (lane & 15);
         const int qy = q >> hp.lgTW, qx = q & (hp.TW - 1);
-        const long m = ((long)n_img * p.H + ty0 + qy) * p.W + tx0 + qx;
-#pragma unroll
-        for (int j = 0; j < CT; j++) {
-            const long o = m * p.K + n0 + wn * 64 + j * 16 + cq;
-            half4_t ev = half4_t{0, 0, 0, 0};
-            if (p.mode) ev = *reinterpret_cast<const half4_t *>(p.extra + o);
-            half4_t out;
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                float v = acc[i][j][e] + (float)bv[j][e];
-                if (p.mode == 1) v += (float)ev[e];
-                v = v > 0.f ? v : v * p.slope;
-                if (p.mode == 2) v += (float)ev[e];
-                out[e] = (_Float16)v;
-            }
-            if (!(dbg & 8)) *reinterpret_cast<half4_t *>(p.y + o) = out;
-        }
-    }
+        return ((long)n_img * p.H + ty0 + qy) * p.W + tx0 + qx;
+    }, !(dbg & 8));
 }
 
 // ------------------------------------------------------------------------------------------------ 3x3 halo, 4 waves
@@ -591,33 +598,12 @@ __global__ __launch_bounds__(256) void k_conv3x3_halo4(const ConvParams p, const
     if (ph < np) step(ph, wfA, xfA, wfB, xfB);
     wait_vmcnt<0>();
 
-    // ---- epilogue from registers
-    const int cq = (lane >> 4) * 4;
-    half4_t bv[CT];
-#pragma unroll
-    for (int j = 0; j < CT; j++) bv[j] = *reinterpret_cast<const half4_t *>(p.bias + n0 + wn * 64 + j * 16 + cq);
-#pragma unroll
-    for (int i = 0; i < PT; i++) {
+    // ---- epilogue from registers (16-byte stores: epilogue_store)
+    epilogue_store<PT, CT>(acc, p, lane, n0 + wn * 64, [&](int i) -> long {
         const int q = wm * 256 + i * 16 + (lane & 15);
         const int qy = q >> hp.lgTW, qx = q & (hp.TW - 1);
-        const long m = ((long)n_img * p.H + ty0 + qy) * p.W + tx0 + qx;
-#pragma unroll
-        for (int j = 0; j < CT; j++) {
-            const long o = m * p.K + n0 + wn * 64 + j * 16 + cq;
-            half4_t ev = half4_t{0, 0, 0, 0};
-            if (p.mode) ev = *reinterpret_cast<const half4_t *>(p.extra + o);
-            half4_t out;
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                float v = acc[i][j][e] + (float)bv[j][e];
-                if (p.mode == 1) v += (float)ev[e];
-                v = v > 0.f ? v : v * p.slope;
-                if (p.mode == 2) v += (float)ev[e];
-                out[e] = (_Float16)v;
-            }
-            *reinterpret_cast<half4_t *>(p.y + o) = out;
-        }
-    }
+        return ((long)n_img * p.H + ty0 + qy) * p.W + tx0 + qx;
+    }, true);
 }
 
 // ------------------------------------------------------------------------------------------------ 3x3 halo, 16 waves
@@ -755,33 +741,12 @@ __global__ __launch_bounds__(1024) void k_conv3x3_halo16(const ConvParams p, con
         }
     }
 
-    // ---- epilogue from registers
-    const int cq = (lane >> 4) * 4;
-    half4_t bv[CT];
-#pragma unroll
-    for (int j = 0; j < CT; j++) bv[j] = *reinterpret_cast<const half4_t *>(p.bias + n0 + wn * 64 + j * 16 + cq);
-#pragma unroll
-    for (int i = 0; i < PT; i++) {
+    // ---- epilogue from registers (16-byte stores: epilogue_store)
+    epilogue_store<PT, CT>(acc, p, lane, n0 + wn * 64, [&](int i) -> long {
         const int q = wm * 64 + i * 16 + (lane & 15);
         const int qy = q >> hp.lgTW, qx = q & (hp.TW - 1);
-        const long m = ((long)n_img * p.H + ty0 + qy) * p.W + tx0 + qx;
-#pragma unroll
-        for (int j = 0; j < CT; j++) {
-            const long o = m * p.K + n0 + wn * 64 + j * 16 + cq;
-            half4_t ev = half4_t{0, 0, 0, 0};
-            if (p.mode) ev = *reinterpret_cast<const half4_t *>(p.extra + o);
-            half4_t out;
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                float v = acc[i][j][e] + (float)bv[j][e];
-                if (p.mode == 1) v += (float)ev[e];
-                v = v > 0.f ? v : v * p.slope;
-                if (p.mode == 2) v += (float)ev[e];
-                out[e] = (_Float16)v;
-            }
-            *reinterpret_cast<half4_t *>(p.y + o) = out;
-        }
-    }
+        return ((long)n_img * p.H + ty0 + qy) * p.W + tx0 + qx;
+    }, true);
 }
 
 void *g_zero_page = nullptr;
@@ -846,7 +811,7 @@ int launch_halo(const ConvParams &p, const HaloParams &g, hipStream_t st) {
         attr_lds = lds;
     }
     const unsigned ptiles = (unsigned)(p.N * g.tiles);
-    const dim3 grid(((ptiles + 7) / 8) * 8 * (unsigned)(p.K / 128));
+    const dim3 grid(((ptiles + 7) / 8) * 8 * (unsigned)(p.K / 128));   // 8 XCD ranges x ceil(ptiles / 8) x channel tiles
     if (p.dbg) hipLaunchKernelGGL((k_conv3x3_halo<128, true>), grid, dim3(NTHREADS), lds, st, p, g);
     else hipLaunchKernelGGL((k_conv3x3_halo<128, false>), grid, dim3(NTHREADS), lds, st, p, g);
     return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
