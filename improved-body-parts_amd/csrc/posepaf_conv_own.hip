@@ -102,6 +102,19 @@ __device__ __forceinline__ void epilogue_store(const float4_t (&acc)[PT][CT], co
 }
 
 template <int N>
+__device__ __forceinline__ void wait_lgkmcnt() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+// Hand-placed matrix instruction and LDS fragment read (see k_conv3x3_halo): the accumulator is tied to its registers.
+__device__ __forceinline__ void mfma_acc(float4_t &c, const half8_t &a, const half8_t &b) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read16(half8_t &dst, unsigned lds_addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "n"(OFF));
+}
+
+template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
@@ -264,16 +277,18 @@ struct HaloParams {
     int HWp, nhalo, npieces;  // halo row length TW + 2, halo pixels, 16-pixel DMA pieces (last one padded)
 };
 
-template <int BN, bool ABLATE>
+template <int BN, int MASK>
 __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, const HaloParams hp) {
-    const int dbg = ABLATE ? p.dbg : 0;  // compile-time 0 in the production instance
+    constexpr int dbg = MASK;  // ablation switches are COMPILE-TIME (a runtime switch costs a branch per guarded instruction); 0 in production
     constexpr int WN = BN / 64;          // 2
     constexpr int WM = 8 / WN;           // 4
     constexpr int PM = TP / WM;          // 128 pixels per wave
     constexpr int PT = PM / 16;          // 8
     constexpr int CT = 4;
     constexpr int WB = BN * 32 * 2;      // weight slice of one phase: 8 sub-tiles, one per wave
-    constexpr int NW = 6;                // weight ring: the slice of phase ph + 4 is issued while phase ph is multiplied
+    constexpr int KEEP = 3;              // phases whose DMA may still be in flight when a phase ends (this one and 2 before)
+    constexpr int NW = 6;                // weight ring
+    constexpr int AHEAD = NW - 1;        // the slice of phase ph + AHEAD is issued while phase ph is multiplied, into the slot phase ph - 1 read
     constexpr int HP = 56;               // halo pieces per buffer: 7 per wave (pieces past the halo are zero-page reads)
     static_assert(BN == 128, "one weight sub-tile per wave and phase");
     extern __shared__ __align__(16) unsigned char smem[];
@@ -305,7 +320,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     // every other group of FOUR pixels.  With it a ds_read_b128 of 16 consecutive pixels x 4 k-groups is bank-conflict free
     // for EVERY start pixel (taps shift the start by 0 / 1 / 2 pixels and by the halo row length); the weight image's
     // swizzle (bit 9) would make 14 of 16 start offsets 2-way conflicted.
-    // Wave w loads pieces w, w + 8, ..., w + 48 of every channel block: two at tap 0, one at taps 1..5 (see the DMA schedule).
+    // Wave w loads pieces w, w + 8, ..., w + 48 of every channel block: two at taps 0..2, one at tap 3 (see the DMA schedule).
     int hsrc[7];   // byte offset inside the image for channel block 0, or -1: zero page (outside the image / past the halo)
 #pragma unroll
     for (int t = 0; t < 7; t++) {
@@ -327,6 +342,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     const int np = ncb * 9;
     int st_cb = 0, st_tap = 0;   // (channel block, tap) of the NEXT weight slice to stage
     int st_slot = 0;
+    int slot_cur = 0;            // ring slot of the phase being multiplied
     auto stage_w = [&]() {
         lds_dma16(wb + woff + ((long)st_tap * p.C + (long)st_cb * 32) * 2, s_w + st_slot * WB + wave * SUB);
         if (++st_slot == NW) st_slot = 0;
@@ -358,71 +374,107 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     };
     auto xaddr = [&](int i, int tapoff_) { return xaddr_from(hb0, i, tapoff_); };
 
-    // ---- prologue: halo of channel block 0 (7 pieces per wave) and the weights of phases 0..3; everything landed
+    // ---- prologue: halo of channel block 0 (7 pieces per wave) and the weight slices of phases 0..AHEAD-1; everything landed
 #pragma unroll
     for (int t = 0; t < 7; t++) stage_halo(t, 0, 0);
-    for (int q = 0; q < 4 && q < np; q++) stage_w();
+    for (int q = 0; q < AHEAD && q < np; q++) stage_w();
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
+    // LDS byte addresses (32-bit) of the two halo buffers and the weight ring, for the hand-placed ds_read_b128 below
+    const unsigned lds_halo = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)s_halo;
+    const unsigned lds_w = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)s_w + wn * 4 * SUB;
     half8_t wf[CT], xf[PT];
+    lds_read16<0>(wf[0], lds_w + wfrag);
+    lds_read16<SUB>(wf[1], lds_w + wfrag);
 #pragma unroll
-    for (int j = 0; j < CT; j++) wf[j] = *reinterpret_cast<const half8_t *>(s_w + (wn * 4 + j) * SUB + wfrag);
-#pragma unroll
-    for (int i = 0; i < PT; i++) xf[i] = *reinterpret_cast<const half8_t *>(s_halo + xaddr(i, 0));
+    for (int i = 0; i < PT; i++) lds_read16<0>(xf[i], lds_halo + xaddr(i, 0));
+    wait_lgkmcnt<0>();
 
     // ---- main loop: channel blocks x 9 taps (unrolled: the DMA count of a tap is a compile-time constant).
-    // In-place fragment refill: the registers hold the fragments of phase ph when its MFMAs start; as soon as the four MFMAs
-    // that use a pixel fragment (and, in the last pixel tile, a weight fragment) have been issued, that register is reloaded
-    // with the SAME fragment of phase ph + 1: one ds_read_b128 every four MFMAs, no second register set, no LDS burst ahead of
-    // the matrix work.
-    // DMA schedule of a wave, per tap: one weight sub-tile (phase ph + 4, ring slot of phase ph - 2), plus, while a next channel
-    // block exists, its halo pieces: two at tap 0, one at taps 1..5, none at 6..8 -- so every halo piece is at least THREE phases
-    // old when tap 8 starts to read the next block's fragments.  After the MFMAs the wave waits until only the DMA of THIS and
-    // the PREVIOUS phase is in flight (counted vmcnt, the count is the schedule's), then the barrier publishes what landed:
-    // the weight slice of phase ph + 2, read one phase later.  No dummy DMA anywhere: a CU's DMA path moves ~1 KiB per 60-85
-    // cycles whatever the bytes are worth, and it is this path, not the matrix pipe, that bounds the implicit-GEMM form.
+    // The MFMAs and fragment reads of a phase are placed BY HAND (asm volatile keeps their order; "+v" keeps every accumulator
+    // in its own four registers -- the compiler's allocation of the builtin form rotated the accumulators through ~50 spare
+    // registers, spilled the fragment address and, because a scratch reload counts in vmcnt like the LDS-DMA, put an
+    // s_waitcnt vmcnt(0) -- i.e. "all DMA landed" -- three times into every phase).
+    // In-place fragment refill, every register reloaded >= 16 MFMAs (256 cycles) before its next use:
+    //   half A: 8 pixel tiles x channel tiles 0, 1;  at its start weight fragments 2, 3 of THIS phase are read (their registers
+    //           became free when the previous phase ended);
+    //   half B: 8 pixel tiles x channel tiles 2, 3;  at its start weight fragments 0, 1 of the NEXT phase are read, and after
+    //           the two MFMAs of pixel tile i its fragment of the next phase (next tap: the same halo, shifted).
+    // LDS returns data in order, so lgkmcnt is counted like vmcnt: before pixel tile i of half A the reads issued after ITS
+    // fragment are tiles i+1..7 of the previous phase and this phase's two weight reads: lgkmcnt(9 - i).
+    // DMA schedule of a wave, per tap: one weight sub-tile (slice ph + AHEAD, into the ring slot phase ph - 1 read from), plus,
+    // while a next channel block exists, its halo pieces: 2, 2, 1, 1, 1 at taps 0..4 -- every piece is KEEP phases old when tap
+    // 7 ends.  After the MFMAs the wave waits until only the DMA of the last KEEP phases is in flight (counted vmcnt; the
+    // count is the schedule's, a compile-time sum), then the barrier publishes what landed: the weight slice of phase ph + 2,
+    // whose fragments 0, 1 are read in half B of the next phase.  No dummy DMA anywhere.
     int ph = 0;
     auto phase = [&](auto TAP, auto HALO, int cb) {
         constexpr int tap = decltype(TAP)::value;
         constexpr bool halo = decltype(HALO)::value;     // a next channel block exists: its halo streams in
         constexpr int ntap = tap == 8 ? 0 : tap + 1;
-        constexpr int c_this = 1 + (halo ? (tap == 0 ? 2 : (tap <= 5 ? 1 : 0)) : 0);
-        constexpr int ptap = tap == 0 ? 8 : tap - 1;
-        // DMA issued by the previous phase: tap - 1 of this block, or tap 8 of the previous block (weights only)
-        constexpr int c_prev = 1 + ((halo && tap != 0) ? (ptap == 0 ? 2 : (ptap <= 5 ? 1 : 0)) : 0);
+        constexpr auto halo_at = [](int t) { return t < 0 ? 0 : (t <= 1 ? 2 : (t <= 4 ? 1 : 0)); };
+        constexpr int in_flight = KEEP + (halo ? halo_at(tap) + halo_at(tap - 1) + halo_at(tap - 2) : 0);
+        static_assert(KEEP == 3, "in_flight sums the halo pieces of three taps");
         if (!(dbg & 1)) {
             if (halo) {
-                if (tap == 0) {
-                    stage_halo(0, cb + 1, (cb + 1) & 1);
-                    stage_halo(6, cb + 1, (cb + 1) & 1);
-                } else if (tap <= 5) {
-                    stage_halo(tap, cb + 1, (cb + 1) & 1);
+                if (tap <= 1) {
+                    stage_halo(2 * tap, cb + 1, (cb + 1) & 1);
+                    stage_halo(2 * tap + 1, cb + 1, (cb + 1) & 1);
+                } else if (tap <= 4) {
+                    stage_halo(tap + 2, cb + 1, (cb + 1) & 1);
                 }
             }
-            if (ph + 4 < np) stage_w();
+            if (ph + AHEAD < np) stage_w();
         }
         const int ncb_ = tap == 8 ? cb + 1 : cb;
-        const bool more = ph + 1 < np;
         constexpr int nr = ntap / 3, nsx = ntap - nr * 3;
         const int ntapoff = (nr * hp.HWp + nsx) * 64;
-        const unsigned char *nsh = s_halo + (ncb_ & 1) * halo_bytes;
-        const unsigned char *nsw = s_w + ((ph + 1) % NW) * WB;
+        const unsigned nsh = lds_halo + (ncb_ & 1) * halo_bytes;
         int base = hb0;
-        asm volatile("" : "+v"(base));   // keeps the 72 per-tap fragment addresses from being hoisted out of the block loop
+        asm volatile("" : "+v"(base));   // keeps the 72 per-tap fragment addresses from being hoisted out of the block loop (and spilled)
+        const unsigned sw_cur = lds_w + slot_cur * WB + wfrag;
+        if (++slot_cur == NW) slot_cur = 0;
+        const unsigned sw_nxt = lds_w + slot_cur * WB + wfrag;
         __builtin_amdgcn_s_setprio(1);
+        if (!(dbg & 4)) {
+            lds_read16<2 * SUB>(wf[2], sw_cur);
+            lds_read16<3 * SUB>(wf[3], sw_cur);
+        }
+        auto tile_a = [&](auto I) {
+            constexpr int i = decltype(I)::value;
+            wait_lgkmcnt<9 - i>();
+            if (!(dbg & 2)) {
+                mfma_acc(acc[i][0], wf[0], xf[i]);
+                mfma_acc(acc[i][1], wf[1], xf[i]);
+            }
+        };
+        tile_a(std::integral_constant<int, 0>{});
+        tile_a(std::integral_constant<int, 1>{});
+        tile_a(std::integral_constant<int, 2>{});
+        tile_a(std::integral_constant<int, 3>{});
+        tile_a(std::integral_constant<int, 4>{});
+        tile_a(std::integral_constant<int, 5>{});
+        tile_a(std::integral_constant<int, 6>{});
+        tile_a(std::integral_constant<int, 7>{});
+        static_assert(PT == 8, "eight pixel tiles per wave");
+        constexpr bool refill = !(dbg & 4) && !(tap == 8 && !halo);   // the last phase of all has no successor (a read whose
+                                                                      // result nobody waits for may land in a re-used register)
+        if (refill) {
+            lds_read16<0>(wf[0], sw_nxt);
+            lds_read16<SUB>(wf[1], sw_nxt);
+        }
+        wait_lgkmcnt<refill ? 2 : 0>();
 #pragma unroll
         for (int i = 0; i < PT; i++) {
-#pragma unroll
-            for (int j = 0; j < CT; j++) {
-                if (!(dbg & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
-                if (i == PT - 1 && more && !(dbg & 4))   // last use of weight fragment j in this phase
-                    wf[j] = *reinterpret_cast<const half8_t *>(nsw + (wn * 4 + j) * SUB + wfrag);
+            if (!(dbg & 2)) {
+                mfma_acc(acc[i][2], wf[2], xf[i]);
+                mfma_acc(acc[i][3], wf[3], xf[i]);
             }
-            if (more && !(dbg & 4)) xf[i] = *reinterpret_cast<const half8_t *>(nsh + xaddr_from(base, i, ntapoff));
+            if (refill) lds_read16<0>(xf[i], nsh + xaddr_from(base, i, ntapoff));
         }
         __builtin_amdgcn_s_setprio(0);
-        if (ph + 4 < np) wait_vmcnt<c_this + c_prev>();
-        else wait_vmcnt<0>();     // the last phases issue no weights: drain (three phases, negligible)
+        if (ph + AHEAD < np) wait_vmcnt<in_flight>();
+        else wait_vmcnt<0>();     // the last phases issue nothing: nothing to wait for
         __builtin_amdgcn_s_barrier();
         ++ph;
     };
@@ -439,6 +491,8 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     };
     for (int cb = 0; cb + 1 < ncb; cb++) block(std::true_type{}, cb);
     block(std::false_type{}, ncb - 1);
+    // the matrix pipe may still be writing the last accumulators: the compiler does not see MFMAs in the asm statements
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 
     // ---- epilogue from registers (16-byte stores: epilogue_store)
     epilogue_store<PT, CT>(acc, p, lane, n0 + wn * 64, [&](int i) -> long {
@@ -799,22 +853,35 @@ int launch_halo4(const ConvParams &p, const HaloParams &g, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
 }
 
-int launch_halo(const ConvParams &p, const HaloParams &g, hipStream_t st) {
+template <int MASK>
+int launch_halo_mask(const ConvParams &p, const HaloParams &g, hipStream_t st) {
     const int lds = 2 * 56 * SUB + 6 * (128 * 32 * 2);   // two halo buffers of 56 pieces, weight ring of 6 slices
-    static int attr_lds = 0;
-    if (lds > attr_lds) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_halo<128, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_halo<128, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_halo<128, MASK>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                lds) != hipSuccess)
             return PP_ERR_HIP;
-        attr_lds = lds;
+        attr_done = true;
     }
     const unsigned ptiles = (unsigned)(p.N * g.tiles);
     const dim3 grid(((ptiles + 7) / 8) * 8 * (unsigned)(p.K / 128));   // 8 XCD ranges x ceil(ptiles / 8) x channel tiles
-    if (p.dbg) hipLaunchKernelGGL((k_conv3x3_halo<128, true>), grid, dim3(NTHREADS), lds, st, p, g);
-    else hipLaunchKernelGGL((k_conv3x3_halo<128, false>), grid, dim3(NTHREADS), lds, st, p, g);
+    hipLaunchKernelGGL((k_conv3x3_halo<128, MASK>), grid, dim3(NTHREADS), lds, st, p, g);
     return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
+}
+
+int launch_halo(const ConvParams &p, const HaloParams &g, hipStream_t st) {
+    switch (p.dbg) {   // POSEPAF_CONV_DBG (diagnostics): compile-time ablated instances; 0 = the product
+        case 0: return launch_halo_mask<0>(p, g, st);
+        case 1: return launch_halo_mask<1>(p, g, st);     // no DMA inside the loop
+        case 2: return launch_halo_mask<2>(p, g, st);     // no MFMA
+        case 4: return launch_halo_mask<4>(p, g, st);     // no fragment reads
+        case 6: return launch_halo_mask<6>(p, g, st);     // DMA + barriers only
+        case 5: return launch_halo_mask<5>(p, g, st);     // MFMA + barriers only
+        case 3: return launch_halo_mask<3>(p, g, st);     // fragment reads + barriers only
+        case 7: return launch_halo_mask<7>(p, g, st);     // barriers only
+        case 15: return launch_halo_mask<15>(p, g, st);   // ... and no epilogue
+        default: return PP_ERR_BAD_ARG;
+    }
 }
 
 template <int BN>

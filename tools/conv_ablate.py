@@ -9,7 +9,7 @@ import torch
 from posepaf import _lib
 L = _lib.load()
 vp = C.c_void_p
-N, ci, co, h, w = 128, 256, 256, 128, 128
+N, ci, co, h, w = 128, int(os.environ.get('CI', '256')), 256, 128, 128
 x = torch.randn(N, ci, h, w, device="cuda").half().contiguous(memory_format=torch.channels_last)
 wt = (torch.randn(co, ci, 3, 3, device="cuda") / (ci * 9) ** 0.5).half().contiguous(memory_format=torch.channels_last)
 b = torch.randn(co, device="cuda").half()
@@ -25,4 +25,4 @@ for _ in range(7):
     e0.record(); L.pp_conv_own_f16(*args); e1.record(); torch.cuda.synchronize()
     ts.append(e0.elapsed_time(e1))
 t = sorted(ts)[3]
-print(f"dbg={os.environ.get('POSEPAF_CONV_DBG', '0'):>2} bn={bn}: {t:.3f} ms  ({2.0 * N * h * w * ci * co * 9 / t / 1e9:.0f} TF-equivalent)")
+print(f"ci={ci} dbg={os.environ.get('POSEPAF_CONV_DBG', '0'):>2} bn={bn}: {t:.3f} ms  ({2.0 * N * h * w * ci * co * 9 / t / 1e9:.0f} TF-equivalent)")
