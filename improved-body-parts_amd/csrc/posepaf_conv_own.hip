@@ -44,6 +44,7 @@ struct ConvParams {
     long M;            // N * Ho * Wo
     int mode;          // 0 none, 1 extra added before the activation, 2 after
     float slope;
+    int stagger;       // persistent 3x3 kernel: start delay of the last workgroup of an XCD, in units of s_sleep(127) (~8100 cycles)
     int dbg;           // ablation switches (POSEPAF_CONV_DBG, diagnostics only): 1 no DMA in the loop, 2 no MFMA, 4 no fragment
                        // reads, 8 no epilogue stores.  0 in production.
 };
@@ -99,6 +100,29 @@ __device__ __forceinline__ void epilogue_store(const float4_t (&acc)[PT][CT], co
             }
         }
     }
+}
+
+// DIAGNOSTIC (MASK bit 64 of k_conv3x3_halo): the epilogue's arithmetic and store COUNT with every store instruction covering
+// 8 pixels x 128 B (full cache lines) instead of 16 pixels x 64 B; the values land at wrong places.  Times the store pattern only.
+template <int PT, int CT, typename PixelOfQ>
+__device__ __forceinline__ void epilogue_fullline_probe(const float4_t (&acc)[PT][CT], const ConvParams &p, int lane, int nbase,
+                                                        PixelOfQ pixel_of_q) {
+    const int co = nbase + (lane >> 3) * 8;
+    const half8_t bv = *reinterpret_cast<const half8_t *>(p.bias + co);
+#pragma unroll
+    for (int jp = 0; jp < CT; jp += 2)
+#pragma unroll
+        for (int i = 0; i < PT; i++) {
+            const long o = pixel_of_q(i * 16 + (jp >> 1) * 8 + (lane & 7)) * p.K + co;
+            half8_t out;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                float t = (e < 4 ? acc[i][jp][e] : acc[i][jp + 1][e - 4]) + (float)bv[e];
+                t = t > 0.f ? t : t * p.slope;
+                out[e] = (_Float16)t;
+            }
+            *reinterpret_cast<half8_t *>(p.y + o) = out;
+        }
 }
 
 template <int N>
@@ -303,40 +327,58 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     // pixel tile are 8 ids apart, so the second one finds the halo its sibling just fetched in L2 (speed only, never needed).
     // Each XCD (ids congruent mod 8) walks a CONTIGUOUS range of pixel tiles, all channel tiles of a pixel tile back to back:
     // the sibling channel tile and the vertically adjacent pixel tile (two shared halo rows) find their input in that L2.
+    // PERSISTENT workgroups: the grid is one workgroup per CU (a multiple of 8); workgroup b takes the ids b, b + grid, ... --
+    // all congruent mod 8, so it stays with "its" XCD's range.  The next tile's first DMA (halo of block 0, five weight slices)
+    // is issued BEFORE the epilogue of the current tile: the output stores drain and the next operands arrive while the
+    // epilogue computes, instead of store drain -> workgroup exit -> dispatch -> DMA latency in a row (a quarter of the time
+    // of the non-persistent form).
     const int nct = p.K / BN;
     const int ptiles = p.N * hp.tiles, per_xcd = (ptiles + 7) >> 3;
-    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-    const int ptile = xcd * per_xcd + q / nct, ctile = q - (q / nct) * nct;
-    if (q / nct >= per_xcd || ptile >= ptiles) return;   // padding of the last range
-    const int n_img = ptile / hp.tiles, tile = ptile - n_img * hp.tiles;
-    const int ty0 = (tile / hp.tiles_x) * hp.TH, tx0 = (tile - (tile / hp.tiles_x) * hp.tiles_x) * hp.TW;
-    const int n0 = ctile * BN;
-    const char *xb = reinterpret_cast<const char *>(p.x) + (long)n_img * p.H * p.W * p.C * 2;   // this image
+    const int total_ids = 8 * per_xcd * nct;
     const char *wb = reinterpret_cast<const char *>(p.w);
     const char *zp = reinterpret_cast<const char *>(p.zero);
-
+    int n_img = 0, ty0 = 0, tx0 = 0, n0 = 0;   // the tile being STAGED (wave-uniform)
+    const char *xb = nullptr;
     // ---- halo DMA sources.  A piece is 16 halo pixels x 64 B, lane-linear in LDS; the swizzle is applied on the source side.
     // Halo swizzle: bit 5 ^= bit 8 of the byte address inside the halo buffer, i.e. the two 32-B halves of a pixel swap on
     // every other group of FOUR pixels.  With it a ds_read_b128 of 16 consecutive pixels x 4 k-groups is bank-conflict free
     // for EVERY start pixel (taps shift the start by 0 / 1 / 2 pixels and by the halo row length); the weight image's
     // swizzle (bit 9) would make 14 of 16 start offsets 2-way conflicted.
-    // Wave w loads pieces w, w + 8, ..., w + 48 of every channel block: two at taps 0..2, one at tap 3 (see the DMA schedule).
+    // Wave w loads pieces w, w + 8, ..., w + 48 of every channel block (see the DMA schedule).
     int hsrc[7];   // byte offset inside the image for channel block 0, or -1: zero page (outside the image / past the halo)
+    long woff = 0; // weight sub-tile of this wave: 16 output channels x 32 halves per phase
+    auto decode = [&](int id) -> bool {   // id -> tile; false: padding of an XCD's range
+        const int xcd = id & 7, q = id >> 3;
+        const int ptile = xcd * per_xcd + q / nct, ctile = q - (q / nct) * nct;
+        if (q / nct >= per_xcd || ptile >= ptiles) return false;
+        n_img = ptile / hp.tiles;
+        const int tile = ptile - n_img * hp.tiles;
+        ty0 = (tile / hp.tiles_x) * hp.TH;
+        tx0 = (tile - (tile / hp.tiles_x) * hp.tiles_x) * hp.TW;
+        n0 = ctile * BN;
+        xb = reinterpret_cast<const char *>(p.x) + (long)n_img * p.H * p.W * p.C * 2;   // this image
+        int ln = lane;
+        asm volatile("" : "+v"(ln));   // recomputed per tile: hoisted, the per-piece halo coordinates would sit in 20 registers
 #pragma unroll
-    for (int t = 0; t < 7; t++) {
-        const int piece = t * 8 + wave;
-        const int phys = piece * SUB + lane * 16;
-        const int logical = phys ^ (((phys >> 8) & 1) << 5);
-        const int hpix = logical >> 6, chunk = (logical >> 4) & 3;
-        const int hy = hpix / hp.HWp, hx = hpix - hy * hp.HWp;
-        const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
-        const bool ok = hpix < hp.nhalo && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        hsrc[t] = ok ? ((iy * p.W + ix) * p.C * 2 + chunk * 16) : -1;
-    }
-    // weight sub-tile of this wave: 16 output channels x 32 halves per phase
-    const int b = lane * 16;
-    const int bs = b ^ (((b >> 9) & 1) << 5);
-    const long woff = (long)(n0 + wave * 16 + (bs >> 6)) * (9L * p.C * 2) + (bs & 63);
+        for (int t = 0; t < 7; t++) {
+            const int piece = t * 8 + wave;
+            const int phys = piece * SUB + ln * 16;
+            const int logical = phys ^ (((phys >> 8) & 1) << 5);
+            const int hpix = logical >> 6, chunk = (logical >> 4) & 3;
+            const int hy = hpix / hp.HWp, hx = hpix - hy * hp.HWp;
+            const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+            const bool ok = hpix < hp.nhalo && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            hsrc[t] = ok ? ((iy * p.W + ix) * p.C * 2 + chunk * 16) : -1;
+        }
+        const int b = ln * 16;
+        const int bs = b ^ (((b >> 9) & 1) << 5);
+        woff = (long)(n0 + wave * 16 + (bs >> 6)) * (9L * p.C * 2) + (bs & 63);
+        return true;
+    };
+    auto next_tile = [&](int id) -> int {   // first valid id at or after `id` on this workgroup's stride, or total_ids
+        while (id < total_ids && !decode(id)) id += gridDim.x;
+        return id;
+    };
 
     const int ncb = p.C / 32;
     const int np = ncb * 9;
@@ -352,16 +394,13 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
         }
     };
     auto stage_halo = [&](int t, int cb, int buf) {   // piece t * 8 + wave (t compile-time 0..6) of channel block cb
-        const uintptr_t src = hsrc[t] >= 0 ? reinterpret_cast<uintptr_t>(xb) + (uintptr_t)((long)hsrc[t] + (long)cb * 64)
-                                           : reinterpret_cast<uintptr_t>(zp);
+        // 32-bit offsets inside the image (< 2^31 bytes: checked by the launcher)
+        int h = hsrc[t];
+        asm volatile("" : "+v"(h));   // opaque: otherwise seven running 64-bit pointers (and their zero-page selects) live in registers
+        const uintptr_t src = h >= 0 ? reinterpret_cast<uintptr_t>(xb) + (uintptr_t)(unsigned)(h + cb * 64)
+                                     : reinterpret_cast<uintptr_t>(zp);
         lds_dma16(reinterpret_cast<const void *>(src), s_halo + buf * halo_bytes + (t * 8 + wave) * SUB);
     };
-
-    float4_t acc[PT][CT];
-#pragma unroll
-    for (int i = 0; i < PT; i++)
-#pragma unroll
-        for (int j = 0; j < CT; j++) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
 
     // fragment addresses.  Weights: sub-tile image as above.  Pixels: lane reads 16 B (k group g) of halo pixel
     // (qy + r) * HWp + qx + s for its output pixel q; pixel tile i starts at tile pixel wm * 128 + 16 i (a multiple of 16 <= TW), so
@@ -373,16 +412,34 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
         return L ^ ((L >> 3) & 32);
     };
     auto xaddr = [&](int i, int tapoff_) { return xaddr_from(hb0, i, tapoff_); };
-
-    // ---- prologue: halo of channel block 0 (7 pieces per wave) and the weight slices of phases 0..AHEAD-1; everything landed
-#pragma unroll
-    for (int t = 0; t < 7; t++) stage_halo(t, 0, 0);
-    for (int q = 0; q < AHEAD && q < np; q++) stage_w();
-    wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
     // LDS byte addresses (32-bit) of the two halo buffers and the weight ring, for the hand-placed ds_read_b128 below
     const unsigned lds_halo = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)s_halo;
     const unsigned lds_w = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)s_w + wn * 4 * SUB;
+
+    // first DMA of a tile: halo of channel block 0 (7 pieces per wave) into buffer 0 and the weight slices of phases 0..AHEAD-1
+    auto stage_first = [&]() {
+        st_cb = 0, st_tap = 0, st_slot = 0;
+#pragma unroll
+        for (int t = 0; t < 7; t++) stage_halo(t, 0, 0);
+        for (int q = 0; q < AHEAD && q < np; q++) stage_w();
+    };
+    int id = next_tile(blockIdx.x);
+    if (id >= total_ids) return;
+    // Start stagger: workgroups of equal work started together reach their epilogues together -- the whole chip stores (HBM
+    // write-bound, matrix pipes idle), then the whole chip multiplies (HBM idle).  Spreading the starts over one tile's time
+    // lets one CU's store burst run under its neighbours' MFMAs.
+    for (int z = (int)(blockIdx.x >> 3) * p.stagger / (int)((gridDim.x + 7) >> 3); z > 0; z--) __builtin_amdgcn_s_sleep(127);
+    stage_first();
+  while (true) {
+    const int c_img = n_img, c_ty0 = ty0, c_tx0 = tx0, c_n0 = n0;   // the tile being COMPUTED
+    float4_t acc[PT][CT];
+#pragma unroll
+    for (int i = 0; i < PT; i++)
+#pragma unroll
+        for (int j = 0; j < CT; j++) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+    wait_vmcnt<0>();     // first DMA of this tile landed (and the previous tile's stores are out)
+    __builtin_amdgcn_s_barrier();
+    slot_cur = 0;
     half8_t wf[CT], xf[PT];
     lds_read16<0>(wf[0], lds_w + wfrag);
     lds_read16<SUB>(wf[1], lds_w + wfrag);
@@ -494,12 +551,25 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     // the matrix pipe may still be writing the last accumulators: the compiler does not see MFMAs in the asm statements
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 
-    // ---- epilogue from registers (16-byte stores: epilogue_store)
-    epilogue_store<PT, CT>(acc, p, lane, n0 + wn * 64, [&](int i) -> long {
+    // ---- next tile's first DMA (every LDS read of this tile is behind the last barrier), then this tile's epilogue from
+    // registers (16-byte stores: epilogue_store)
+    id = next_tile(id + gridDim.x);
+    const bool has_next = id < total_ids;
+    if (has_next) stage_first();
+    if (dbg & 64)
+        epilogue_fullline_probe<PT, CT>(acc, p, lane, c_n0 + wn * 64, [&](int qq) -> long {
+            const int q = wm * PM + qq;
+            const int qy = q >> hp.lgTW, qx = q & (hp.TW - 1);
+            return ((long)c_img * p.H + c_ty0 + qy) * p.W + c_tx0 + qx;
+        });
+    else
+    epilogue_store<PT, CT>(acc, p, lane, c_n0 + wn * 64, [&](int i) -> long {
         const int q = wm * PM + i * 16 + (lane & 15);
         const int qy = q >> hp.lgTW, qx = q & (hp.TW - 1);
-        return ((long)n_img * p.H + ty0 + qy) * p.W + tx0 + qx;
+        return ((long)c_img * p.H + c_ty0 + qy) * p.W + c_tx0 + qx;
     }, !(dbg & 8));
+    if (!has_next) break;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ 3x3 halo, 4 waves
@@ -808,6 +878,7 @@ void *g_zero_page = nullptr;
 // geometry of the halo kernel for an image size, or false when the shape is not taken (the implicit-GEMM kernel runs it)
 bool halo_geometry(const ConvParams &p, HaloParams &g) {
     if (p.R != 3 || p.pad != 1 || p.dil != 1 || p.C % 32 || p.K % 128) return false;
+    if ((long)p.H * p.W * p.C * 2 >= (1L << 31)) return false;   // 32-bit byte offsets inside one image
     int tw = p.W < 128 ? p.W : 128;
     if (tw < 16 || (tw & (tw - 1)) || p.W % tw) return false;
     const int th = TP / tw;
@@ -864,8 +935,25 @@ int launch_halo_mask(const ConvParams &p, const HaloParams &g, hipStream_t st) {
         attr_done = true;
     }
     const unsigned ptiles = (unsigned)(p.N * g.tiles);
-    const dim3 grid(((ptiles + 7) / 8) * 8 * (unsigned)(p.K / 128));   // 8 XCD ranges x ceil(ptiles / 8) x channel tiles
-    hipLaunchKernelGGL((k_conv3x3_halo<128, MASK>), grid, dim3(NTHREADS), lds, st, p, g);
+    const unsigned ids = ((ptiles + 7) / 8) * 8 * (unsigned)(p.K / 128);   // 8 XCD ranges x ceil(ptiles / 8) x channel tiles
+    static int ncu = 0;      // persistent grid: one workgroup per CU (160 KiB of LDS each), a multiple of 8
+    static bool persist = true;
+    if (ncu == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            return PP_ERR_HIP;
+        ncu = ncu >= 8 ? (ncu / 8) * 8 : 8;
+        const char *e = getenv("POSEPAF_CONV_PERSIST");   // diagnostics: 0 = one tile per workgroup
+        persist = !(e && e[0] == '0');
+    }
+    const dim3 grid(persist && ids > (unsigned)ncu ? (unsigned)ncu : ids);
+    ConvParams q = p;
+    if (q.stagger < 0) {   // default: spread the starts over half a tile's time (np phases of ~1500 cycles), less when a workgroup has few tiles
+        const float rounds = (float)ids / (float)grid.x;
+        const float f = 0.5f * (rounds < 32.f ? rounds / 32.f : 1.f);
+        q.stagger = grid.x < ids ? (int)(f * (float)(p.C / 32 * 9) * 1500.f / 8128.f + 0.5f) : 0;
+    }
+    hipLaunchKernelGGL((k_conv3x3_halo<128, MASK>), grid, dim3(NTHREADS), lds, st, q, g);
     return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
 }
 
@@ -880,6 +968,8 @@ int launch_halo(const ConvParams &p, const HaloParams &g, hipStream_t st) {
         case 3: return launch_halo_mask<3>(p, g, st);     // fragment reads + barriers only
         case 7: return launch_halo_mask<7>(p, g, st);     // barriers only
         case 15: return launch_halo_mask<15>(p, g, st);   // ... and no epilogue
+        case 64: return launch_halo_mask<64>(p, g, st);   // full-line store pattern (wrong placement: timing only)
+        case 71: return launch_halo_mask<71>(p, g, st);   // ... with barriers only
         default: return PP_ERR_BAD_ARG;
     }
 }
@@ -934,6 +1024,8 @@ PP_API int pp_conv_own_f16(const void *x, const void *w, const void *bias, const
     p.slope = slope;
     static const int dbg = std::getenv("POSEPAF_CONV_DBG") ? std::atoi(std::getenv("POSEPAF_CONV_DBG")) : 0;
     p.dbg = dbg;
+    static const int stagger = std::getenv("POSEPAF_CONV_STAGGER") ? std::atoi(std::getenv("POSEPAF_CONV_STAGGER")) : -1;   // -1: launcher's default
+    p.stagger = stagger;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (bn == 0 || bn == 512 || bn == 514 || bn == 516) {   // 512 / 514 / 516: the halo-tile 3x3 kernels (8 / 4 / 16 waves)
         HaloParams g;
