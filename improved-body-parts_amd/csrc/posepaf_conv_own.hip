@@ -62,44 +62,65 @@ __device__ __forceinline__ void lds_dma16(const void *gsrc, unsigned char *lds_w
 // cross-lane exchange of four accumulators each way), and every lane then finishes eight consecutive channels -- bias,
 // residual, LeakyReLU, post add in fp32, one 16-byte load of `extra`, one 16-byte store: half the memory instructions.
 // pixel_of(i): flat output pixel index of this lane in pixel tile i, or -1 (outside the tensor).
-template <int PT, int CT, typename PixelOf>
-__device__ __forceinline__ void epilogue_store(const float4_t (&acc)[PT][CT], const ConvParams &p, int lane, int nbase,
-                                               PixelOf pixel_of, bool do_store) {
+typedef float float2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+
+template <int MODE, int PT, int CT, typename PixelOf>
+__device__ __forceinline__ void epilogue_body(const float4_t (&acc)[PT][CT], const ConvParams &p, int lane, int nbase,
+                                              PixelOf pixel_of, bool do_store) {
     static_assert(CT % 2 == 0, "channel tiles are finished in pairs");
     const int g = lane >> 4, odd = g & 1, cbase = (g & ~1) * 4;
+    const float2_t slope2 = float2_t{p.slope, p.slope};
 #pragma unroll
     for (int jp = 0; jp < CT; jp += 2) {
         const int co = nbase + (jp + odd) * 16 + cbase;
         const half8_t bv = *reinterpret_cast<const half8_t *>(p.bias + co);
+        float2_t b2[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) b2[e] = float2_t{(float)bv[2 * e], (float)bv[2 * e + 1]};
 #pragma unroll
         for (int i = 0; i < PT; i++) {
             float v[8];
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                const float keep = odd ? acc[i][jp + 1][e] : acc[i][jp][e];
-                const float send = odd ? acc[i][jp][e] : acc[i][jp + 1][e];
-                const float recv = __shfl_xor(send, 16);
-                v[e] = odd ? recv : keep;       // the lower quad comes from the even-quad lane
-                v[4 + e] = odd ? keep : recv;
+                // v_permlane16_swap: the odd 16-lane rows of the first operand change places with the even rows of the second.
+                // Afterwards the first holds, in even rows, the own quad of tile jp and, in odd rows, the lower neighbour's quad of
+                // tile jp + 1; the second the upper neighbour's quad of tile jp (even rows) and the own quad of tile jp + 1 (odd).
+                const float a0 = acc[i][jp][e], a1 = acc[i][jp + 1][e];   // (bit_cast straight from the vector element miscompiles)
+                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(a0), __float_as_uint(a1), false, false);
+                v[e] = __builtin_bit_cast(float, (unsigned)sw[0]);
+                v[4 + e] = __builtin_bit_cast(float, (unsigned)sw[1]);
             }
             const long m = pixel_of(i);
             if (m >= 0) {
                 const long o = m * p.K + co;
                 half8_t ev = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
-                if (p.mode) ev = *reinterpret_cast<const half8_t *>(p.extra + o);
+                if (MODE) ev = *reinterpret_cast<const half8_t *>(p.extra + o);
                 half8_t out;
 #pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    float t = v[e] + (float)bv[e];
-                    if (p.mode == 1) t += (float)ev[e];
-                    t = t > 0.f ? t : t * p.slope;
-                    if (p.mode == 2) t += (float)ev[e];
-                    out[e] = (_Float16)t;
+                for (int e = 0; e < 4; e++) {   // two channels at a time: v_pk_add_f32 / v_pk_mul_f32
+                    float2_t t = float2_t{v[2 * e], v[2 * e + 1]} + b2[e];
+                    const float2_t x = float2_t{(float)ev[2 * e], (float)ev[2 * e + 1]};
+                    if (MODE == 1) t += x;
+                    const float2_t u = t * slope2;   // LeakyReLU for 0 <= slope <= 1 (checked by the launcher); slope 1: none
+                    t = float2_t{fmaxf(t[0], u[0]), fmaxf(t[1], u[1])};
+                    if (MODE == 2) t += x;
+                    out[2 * e] = (_Float16)t[0];
+                    out[2 * e + 1] = (_Float16)t[1];
                 }
                 if (do_store) *reinterpret_cast<half8_t *>(p.y + o) = out;
             }
         }
     }
+}
+
+template <int PT, int CT, typename PixelOf>
+__device__ __forceinline__ void epilogue_store(const float4_t (&acc)[PT][CT], const ConvParams &p, int lane, int nbase,
+                                               PixelOf pixel_of, bool do_store) {
+    // the residual mode is wave-uniform: three bodies, one scalar branch, no per-element selects
+    if (p.mode == 0) epilogue_body<0, PT, CT>(acc, p, lane, nbase, pixel_of, do_store);
+    else if (p.mode == 1) epilogue_body<1, PT, CT>(acc, p, lane, nbase, pixel_of, do_store);
+    else epilogue_body<2, PT, CT>(acc, p, lane, nbase, pixel_of, do_store);
 }
 
 // DIAGNOSTIC (MASK bit 64 of k_conv3x3_halo): the epilogue's arithmetic and store COUNT with every store instruction covering
@@ -301,6 +322,9 @@ struct HaloParams {
     int HWp, nhalo, npieces;  // halo row length TW + 2, halo pixels, 16-pixel DMA pieces (last one padded)
 };
 
+// DIAGNOSTIC (MASK bit 1024): shader clock / 100 MHz reference clock stamps around the main loop of each workgroup's first tile
+__device__ unsigned long long g_conv_clk[8 * 512];
+
 template <int BN, int MASK>
 __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, const HaloParams hp) {
     constexpr int dbg = MASK;  // ablation switches are COMPILE-TIME (a runtime switch costs a branch per guarded instruction); 0 in production
@@ -423,6 +447,14 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
         for (int t = 0; t < 7; t++) stage_halo(t, 0, 0);
         for (int q = 0; q < AHEAD && q < np; q++) stage_w();
     };
+    unsigned long long acc_t[6] = {0, 0, 0, 0, 0, 0}, t_prev = 0;   // DIAGNOSTIC (MASK bit 1024): cycles per section, summed over tiles
+    auto stamp = [&](int k) {
+        if (dbg & 1024) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (k >= 0) acc_t[k] += t - t_prev;
+            t_prev = t;
+        }
+    };
     int id = next_tile(blockIdx.x);
     if (id >= total_ids) return;
     // Start stagger: workgroups of equal work started together reach their epilogues together -- the whole chip stores (HBM
@@ -437,8 +469,10 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     for (int i = 0; i < PT; i++)
 #pragma unroll
         for (int j = 0; j < CT; j++) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+    stamp(-1);
     wait_vmcnt<0>();     // first DMA of this tile landed (and the previous tile's stores are out)
     __builtin_amdgcn_s_barrier();
+    stamp(0);            // 0: wait for first DMA + stores, barrier
     slot_cur = 0;
     half8_t wf[CT], xf[PT];
     lds_read16<0>(wf[0], lds_w + wfrag);
@@ -465,6 +499,10 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     // count is the schedule's, a compile-time sum), then the barrier publishes what landed: the weight slice of phase ph + 2,
     // whose fragments 0, 1 are read in half B of the next phase.  No dummy DMA anywhere.
     int ph = 0;
+    const int grp = wave >> 2;   // waves w and w + 4 share a SIMD
+    unsigned long long rt0 = 0;
+    if (dbg & 1024) rt0 = __builtin_amdgcn_s_memrealtime();
+    stamp(1);            // 1: first fragment reads
     auto phase = [&](auto TAP, auto HALO, int cb) {
         constexpr int tap = decltype(TAP)::value;
         constexpr bool halo = decltype(HALO)::value;     // a next channel block exists: its halo streams in
@@ -472,17 +510,22 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
         constexpr auto halo_at = [](int t) { return t < 0 ? 0 : (t <= 1 ? 2 : (t <= 4 ? 1 : 0)); };
         constexpr int in_flight = KEEP + (halo ? halo_at(tap) + halo_at(tap - 1) + halo_at(tap - 2) : 0);
         static_assert(KEEP == 3, "in_flight sums the halo pieces of three taps");
-        if (!(dbg & 1)) {
-            if (halo) {
-                if (tap <= 1) {
-                    stage_halo(2 * tap, cb + 1, (cb + 1) & 1);
-                    stage_halo(2 * tap + 1, cb + 1, (cb + 1) & 1);
-                } else if (tap <= 4) {
-                    stage_halo(tap + 2, cb + 1, (cb + 1) & 1);
+        // The two waves of a SIMD (w and w + 4) issue their DMA at different times: a piece blocks its wave for 60-100 cycles, and
+        // with both waves there at once right after the barrier the matrix pipe idles; group 1 issues between the halves.
+        auto issue_dma = [&]() {
+            if (!(dbg & 1)) {
+                if (halo) {
+                    if (tap <= 1) {
+                        stage_halo(2 * tap, cb + 1, (cb + 1) & 1);
+                        stage_halo(2 * tap + 1, cb + 1, (cb + 1) & 1);
+                    } else if (tap <= 4) {
+                        stage_halo(tap + 2, cb + 1, (cb + 1) & 1);
+                    }
                 }
+                if (ph + AHEAD < np) stage_w();
             }
-            if (ph + AHEAD < np) stage_w();
-        }
+        };
+        if (grp == 0 || (dbg & 128)) issue_dma();
         const int ncb_ = tap == 8 ? cb + 1 : cb;
         constexpr int nr = ntap / 3, nsx = ntap - nr * 3;
         const int ntapoff = (nr * hp.HWp + nsx) * 64;
@@ -516,6 +559,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
         static_assert(PT == 8, "eight pixel tiles per wave");
         constexpr bool refill = !(dbg & 4) && !(tap == 8 && !halo);   // the last phase of all has no successor (a read whose
                                                                       // result nobody waits for may land in a re-used register)
+        if (grp != 0 && !(dbg & 128)) issue_dma();
         if (refill) {
             lds_read16<0>(wf[0], sw_nxt);
             lds_read16<SUB>(wf[1], sw_nxt);
@@ -550,12 +594,15 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     block(std::false_type{}, ncb - 1);
     // the matrix pipe may still be writing the last accumulators: the compiler does not see MFMAs in the asm statements
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    stamp(2);            // 2: main loop
+    if (dbg & 1024) acc_t[5] += __builtin_amdgcn_s_memrealtime() - rt0;   // 5: main loop in 100 MHz ticks
 
     // ---- next tile's first DMA (every LDS read of this tile is behind the last barrier), then this tile's epilogue from
     // registers (16-byte stores: epilogue_store)
     id = next_tile(id + gridDim.x);
     const bool has_next = id < total_ids;
     if (has_next) stage_first();
+    stamp(3);            // 3: next tile's decode + first DMA issue
     if (dbg & 64)
         epilogue_fullline_probe<PT, CT>(acc, p, lane, c_n0 + wn * 64, [&](int qq) -> long {
             const int q = wm * PM + qq;
@@ -568,8 +615,11 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
         const int qy = q >> hp.lgTW, qx = q & (hp.TW - 1);
         return ((long)c_img * p.H + c_ty0 + qy) * p.W + c_tx0 + qx;
     }, !(dbg & 8));
+    stamp(4);            // 4: epilogue (issue)
     if (!has_next) break;
   }
+    if ((dbg & 1024) && threadIdx.x == 0 && blockIdx.x < 512)
+        for (int k = 0; k < 6; k++) g_conv_clk[blockIdx.x * 8 + k] = acc_t[k];
 }
 
 // ------------------------------------------------------------------------------------------------ 3x3 halo, 4 waves
@@ -970,6 +1020,10 @@ int launch_halo(const ConvParams &p, const HaloParams &g, hipStream_t st) {
         case 15: return launch_halo_mask<15>(p, g, st);   // ... and no epilogue
         case 64: return launch_halo_mask<64>(p, g, st);   // full-line store pattern (wrong placement: timing only)
         case 71: return launch_halo_mask<71>(p, g, st);   // ... with barriers only
+        case 1152: return launch_halo_mask<1152>(p, g, st);   // stamps, both waves of a SIMD issue DMA at the phase start
+        case 1024: return launch_halo_mask<1024>(p, g, st);   // in-kernel clock stamps (pp_conv_debug_clock)
+        case 1028: return launch_halo_mask<1028>(p, g, st);
+        case 1029: return launch_halo_mask<1029>(p, g, st);
         default: return PP_ERR_BAD_ARG;
     }
 }
@@ -994,6 +1048,27 @@ int launch(const ConvParams &p, hipStream_t st) {
 extern "C" {
 
 // 1 when pp_conv_own_f16 takes the shape: stride 1, square kernel, C_in % 64 == 0, C_out % 64 == 0
+// Diagnostics (POSEPAF_CONV_DBG with bit 1024): median over workgroups of the shader-clock cycles a workgroup spent per section,
+// summed over its tiles, in the last stamped launch.  out[0..4] = wait for first DMA + stores / first fragment reads / main loop /
+// next tile's decode + DMA issue / epilogue; out[5] = main loop in 100 MHz ticks (clock in GHz = out[2] / out[5] / 10).
+PP_API int pp_conv_debug_clock(double *out, int nwg) {
+    static unsigned long long h[8 * 512];
+    if (!out || nwg <= 0 || nwg > 512) return PP_ERR_BAD_ARG;
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_conv_clk), sizeof(h)) != hipSuccess) return PP_ERR_HIP;
+    for (int k = 0; k < 6; k++) {   // median over workgroups of each section's cycle sum
+        double v[512];
+        for (int i = 0; i < nwg; i++) v[i] = (double)h[i * 8 + k];
+        for (int i = 1; i < nwg; i++) {
+            const double x = v[i];
+            int j = i - 1;
+            for (; j >= 0 && v[j] > x; j--) v[j + 1] = v[j];
+            v[j + 1] = x;
+        }
+        out[k] = v[nwg / 2];
+    }
+    return PP_OK;
+}
+
 PP_API int pp_conv_own_supported(int c_in, int c_out, int ksize) { return (c_in % 32 == 0 && c_out % 64 == 0 && ksize >= 1 && ksize <= 7) ? 1 : 0; }
 
 PP_API int pp_conv_own_f16(const void *x, const void *w, const void *bias, const void *extra, void *y, int n, int h, int wd, int c_in,
@@ -1002,6 +1077,7 @@ PP_API int pp_conv_own_f16(const void *x, const void *w, const void *bias, const
         extra_mode > 2 || (extra_mode != 0) != (extra != nullptr))
         return PP_ERR_BAD_ARG;
     if (!pp_conv_own_supported(c_in, c_out, ksize)) return PP_ERR_UNSUPPORTED;
+    if (!(slope >= 0.f && slope <= 1.f)) return PP_ERR_UNSUPPORTED;   // the epilogue's LeakyReLU is max(t, slope * t)
     const uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(bias) |
                          reinterpret_cast<uintptr_t>(extra) | reinterpret_cast<uintptr_t>(y);
     if (al & 15) return PP_ERR_BAD_ARG;

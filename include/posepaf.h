@@ -188,6 +188,11 @@ PP_API int pp_conv_f16(const void *x, const void *w, const void *bias, const voi
  * from registers; no composable_kernel).  Needs c_in % 64 == 0 and c_out % 64 == 0 (pp_conv_own_supported).  bn = output
  * channels per workgroup: 256, 128 or 64 (must divide c_out), 0 = the largest that divides c_out. */
 PP_API int pp_conv_own_supported(int c_in, int c_out, int ksize);
+/* Diagnostics: after a launch of the 3x3 halo kernel with POSEPAF_CONV_DBG bit 1024 set, the median over the first nwg
+ * workgroups of the shader-clock cycles spent per section (summed over the workgroup's tiles): out6[0..4] = wait for the
+ * first DMA and the previous stores / first fragment reads / main loop / next tile's decode + DMA issue / epilogue;
+ * out6[5] = the main loop in 100 MHz ticks.  No reference counterpart. */
+PP_API int pp_conv_debug_clock(double *out6, int nwg);
 PP_API int pp_conv_own_f16(const void *x, const void *w, const void *bias, const void *extra, void *y, int n, int h, int wd,
                            int c_in, int c_out, int ksize, int pad, int dilation, int extra_mode, float slope, int bn,
                            void *stream);

@@ -25,4 +25,17 @@ for _ in range(7):
     e0.record(); L.pp_conv_own_f16(*args); e1.record(); torch.cuda.synchronize()
     ts.append(e0.elapsed_time(e1))
 t = sorted(ts)[3]
+if int(os.environ.get('POSEPAF_CONV_DBG', '0')) & 1024:
+    for _ in range(300):   # clocks settle under sustained load
+        L.pp_conv_own_f16(*args)
+    torch.cuda.synchronize()
+    out = (C.c_double * 6)()
+    L.pp_conv_debug_clock.argtypes = [C.POINTER(C.c_double), C.c_int]
+    assert L.pp_conv_debug_clock(out, 256) == 0
+    ghz = out[2] / out[5] / 10
+    tot = sum(out[:5])
+    names = ["wait first DMA + stores", "first fragment reads", "main loop", "next decode + DMA issue", "epilogue issue"]
+    print(f"  in-kernel clock {ghz:.3f} GHz (main loop); per workgroup, all its tiles: {tot / ghz / 1e3:.1f} us")
+    for nm, v in zip(names, out[:5]):
+        print(f"    {nm:26s} {v / ghz / 1e3:8.1f} us  {100 * v / tot:5.1f} %")
 print(f"ci={ci} dbg={os.environ.get('POSEPAF_CONV_DBG', '0'):>2} bn={bn}: {t:.3f} ms  ({2.0 * N * h * w * ci * co * 9 / t / 1e9:.0f} TF-equivalent)")
