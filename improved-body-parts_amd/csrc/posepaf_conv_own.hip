@@ -325,8 +325,10 @@ struct HaloParams {
 // DIAGNOSTIC (MASK bit 1024): shader clock / 100 MHz reference clock stamps around the main loop of each workgroup's first tile
 __device__ unsigned long long g_conv_clk[8 * 512];
 
-template <int BN, int MASK>
+template <int BN, int MASK, int LGTW>
 __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, const HaloParams hp) {
+    // The tile geometry is a template parameter: every fragment address is then "lane register + immediate" (see R[][] below).
+    constexpr int TW = 1 << LGTW, HWp = TW + 2, TH = TP / TW, NHALO = (TH + 2) * HWp;
     constexpr int dbg = MASK;  // ablation switches are COMPILE-TIME (a runtime switch costs a branch per guarded instruction); 0 in production
     constexpr int WN = BN / 64;          // 2
     constexpr int WM = 8 / WN;           // 4
@@ -377,8 +379,8 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
         if (q / nct >= per_xcd || ptile >= ptiles) return false;
         n_img = ptile / hp.tiles;
         const int tile = ptile - n_img * hp.tiles;
-        ty0 = (tile / hp.tiles_x) * hp.TH;
-        tx0 = (tile - (tile / hp.tiles_x) * hp.tiles_x) * hp.TW;
+        ty0 = (tile / hp.tiles_x) * TH;
+        tx0 = (tile - (tile / hp.tiles_x) * hp.tiles_x) * TW;
         n0 = ctile * BN;
         xb = reinterpret_cast<const char *>(p.x) + (long)n_img * p.H * p.W * p.C * 2;   // this image
         int ln = lane;
@@ -389,9 +391,9 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
             const int phys = piece * SUB + ln * 16;
             const int logical = phys ^ (((phys >> 8) & 1) << 5);
             const int hpix = logical >> 6, chunk = (logical >> 4) & 3;
-            const int hy = hpix / hp.HWp, hx = hpix - hy * hp.HWp;
+            const int hy = hpix / HWp, hx = hpix - hy * HWp;
             const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
-            const bool ok = hpix < hp.nhalo && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const bool ok = hpix < NHALO && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
             hsrc[t] = ok ? ((iy * p.W + ix) * p.C * 2 + chunk * 16) : -1;
         }
         const int b = ln * 16;
@@ -427,18 +429,39 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     };
 
     // fragment addresses.  Weights: sub-tile image as above.  Pixels: lane reads 16 B (k group g) of halo pixel
-    // (qy + r) * HWp + qx + s for its output pixel q; pixel tile i starts at tile pixel wm * 128 + 16 i (a multiple of 16 <= TW), so
-    // its halo offset relative to tile 0 is wave-uniform: ONE vector register holds the lane part.
+    // (qy + r) * HWp + qx + s for its output pixel q; pixel tile i starts at tile pixel wm * 128 + 16 i (a multiple of 16 <= TW).
+    // With L = hb0 + C the unswizzled byte offset (hb0 the lane part, C = 64 x the pixel offset of (tap, pixel tile): compile-time),
+    // the swizzled address L ^ (bit8(L) << 5) equals  (swz(hb0 + 64 k) ^ (f << 5)) + Chi  with k = (C / 64) & 3, Chi = C & ~255,
+    // f = bit 8 of Chi -- adding a multiple of 256 neither carries into bit 8 from below nor touches bit 5.  Eight lane registers
+    // R[k][f] (set up per tile, moved to the other halo buffer per channel block) and the 16-bit immediate offset Chi: a
+    // fragment read costs NO address arithmetic (it was four VALU instructions per read, 32 per wave and phase).
     const int wfrag = (lane & 15) * 64 + (((lane >> 4) * 16) ^ (((lane & 15) >> 3) << 5));
-    const int hb0 = (((wm * PM) >> hp.lgTW) * hp.HWp + ((wm * PM) & (hp.TW - 1)) + (lane & 15)) * 64 + (lane >> 4) * 16;
-    auto xaddr_from = [&](int base, int i, int tapoff_) {
-        const int L = base + tapoff_ + ((((i * 16) >> hp.lgTW) * hp.HWp + ((i * 16) & (hp.TW - 1))) * 64);
-        return L ^ ((L >> 3) & 32);
-    };
-    auto xaddr = [&](int i, int tapoff_) { return xaddr_from(hb0, i, tapoff_); };
+    const int hb0 = (((wm * PM) >> LGTW) * HWp + ((wm * PM) & (TW - 1)) + (lane & 15)) * 64 + (lane >> 4) * 16;
     // LDS byte addresses (32-bit) of the two halo buffers and the weight ring, for the hand-placed ds_read_b128 below
     const unsigned lds_halo = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)s_halo;
     const unsigned lds_w = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)s_w + wn * 4 * SUB;
+    unsigned R[4][2];
+    auto set_R = [&]() {   // for halo buffer 0
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int M = hb0 + k * 64;
+            const unsigned a = lds_halo + (unsigned)(M ^ ((M >> 3) & 32));
+            R[k][0] = a;
+            R[k][1] = a ^ 32u;
+        }
+    };
+    auto flip_R = [&](int to_buf) {   // to the other halo buffer
+        const unsigned d = to_buf ? (unsigned)halo_bytes : (unsigned)-halo_bytes;
+#pragma unroll
+        for (int k = 0; k < 4; k++) R[k][0] += d, R[k][1] += d;
+    };
+    auto xread = [&](auto TAP, auto I, half8_t &dst) {   // pixel fragment of (tap, pixel tile i) from the halo buffer R points to
+        constexpr int tap = decltype(TAP)::value, i = decltype(I)::value;
+        constexpr int Cpix = (tap / 3) * HWp + tap % 3 + ((i * 16) >> LGTW) * HWp + ((i * 16) & (TW - 1));
+        constexpr int C = Cpix * 64, k = Cpix & 3, Chi = C & ~255, f = (Chi >> 8) & 1;
+        static_assert(Chi < 65536, "16-bit DS offset");
+        lds_read16<Chi>(dst, R[k][f]);
+    };
 
     // first DMA of a tile: halo of channel block 0 (7 pieces per wave) into buffer 0 and the weight slices of phases 0..AHEAD-1
     auto stage_first = [&]() {
@@ -475,10 +498,18 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     stamp(0);            // 0: wait for first DMA + stores, barrier
     slot_cur = 0;
     half8_t wf[CT], xf[PT];
+    set_R();
     lds_read16<0>(wf[0], lds_w + wfrag);
     lds_read16<SUB>(wf[1], lds_w + wfrag);
-#pragma unroll
-    for (int i = 0; i < PT; i++) lds_read16<0>(xf[i], lds_halo + xaddr(i, 0));
+    using T0 = std::integral_constant<int, 0>;
+    xread(T0{}, std::integral_constant<int, 0>{}, xf[0]);
+    xread(T0{}, std::integral_constant<int, 1>{}, xf[1]);
+    xread(T0{}, std::integral_constant<int, 2>{}, xf[2]);
+    xread(T0{}, std::integral_constant<int, 3>{}, xf[3]);
+    xread(T0{}, std::integral_constant<int, 4>{}, xf[4]);
+    xread(T0{}, std::integral_constant<int, 5>{}, xf[5]);
+    xread(T0{}, std::integral_constant<int, 6>{}, xf[6]);
+    xread(T0{}, std::integral_constant<int, 7>{}, xf[7]);
     wait_lgkmcnt<0>();
 
     // ---- main loop: channel blocks x 9 taps (unrolled: the DMA count of a tap is a compile-time constant).
@@ -526,12 +557,6 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
             }
         };
         if (grp == 0 || (dbg & 128)) issue_dma();
-        const int ncb_ = tap == 8 ? cb + 1 : cb;
-        constexpr int nr = ntap / 3, nsx = ntap - nr * 3;
-        const int ntapoff = (nr * hp.HWp + nsx) * 64;
-        const unsigned nsh = lds_halo + (ncb_ & 1) * halo_bytes;
-        int base = hb0;
-        asm volatile("" : "+v"(base));   // keeps the 72 per-tap fragment addresses from being hoisted out of the block loop (and spilled)
         const unsigned sw_cur = lds_w + slot_cur * WB + wfrag;
         if (++slot_cur == NW) slot_cur = 0;
         const unsigned sw_nxt = lds_w + slot_cur * WB + wfrag;
@@ -565,14 +590,23 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
             lds_read16<SUB>(wf[1], sw_nxt);
         }
         wait_lgkmcnt<refill ? 2 : 0>();
-#pragma unroll
-        for (int i = 0; i < PT; i++) {
+        if (refill && tap == 8) flip_R((cb + 1) & 1);   // the next phase is tap 0 of the next channel block: the other halo buffer
+        auto tile_b = [&](auto I) {
+            constexpr int i = decltype(I)::value;
             if (!(dbg & 2)) {
                 mfma_acc(acc[i][2], wf[2], xf[i]);
                 mfma_acc(acc[i][3], wf[3], xf[i]);
             }
-            if (refill) lds_read16<0>(xf[i], nsh + xaddr_from(base, i, ntapoff));
-        }
+            if (refill) xread(std::integral_constant<int, ntap>{}, I, xf[i]);
+        };
+        tile_b(std::integral_constant<int, 0>{});
+        tile_b(std::integral_constant<int, 1>{});
+        tile_b(std::integral_constant<int, 2>{});
+        tile_b(std::integral_constant<int, 3>{});
+        tile_b(std::integral_constant<int, 4>{});
+        tile_b(std::integral_constant<int, 5>{});
+        tile_b(std::integral_constant<int, 6>{});
+        tile_b(std::integral_constant<int, 7>{});
         __builtin_amdgcn_s_setprio(0);
         if (ph + AHEAD < np) wait_vmcnt<in_flight>();
         else wait_vmcnt<0>();     // the last phases issue nothing: nothing to wait for
@@ -606,13 +640,13 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     if (dbg & 64)
         epilogue_fullline_probe<PT, CT>(acc, p, lane, c_n0 + wn * 64, [&](int qq) -> long {
             const int q = wm * PM + qq;
-            const int qy = q >> hp.lgTW, qx = q & (hp.TW - 1);
+            const int qy = q >> LGTW, qx = q & (TW - 1);
             return ((long)c_img * p.H + c_ty0 + qy) * p.W + c_tx0 + qx;
         });
     else
     epilogue_store<PT, CT>(acc, p, lane, c_n0 + wn * 64, [&](int i) -> long {
         const int q = wm * PM + i * 16 + (lane & 15);
-        const int qy = q >> hp.lgTW, qx = q & (hp.TW - 1);
+        const int qy = q >> LGTW, qx = q & (TW - 1);
         return ((long)c_img * p.H + c_ty0 + qy) * p.W + c_tx0 + qx;
     }, !(dbg & 8));
     stamp(4);            // 4: epilogue (issue)
@@ -974,12 +1008,12 @@ int launch_halo4(const ConvParams &p, const HaloParams &g, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
 }
 
-template <int MASK>
-int launch_halo_mask(const ConvParams &p, const HaloParams &g, hipStream_t st) {
+template <int MASK, int LGTW>
+int launch_halo_inst(const ConvParams &p, const HaloParams &g, hipStream_t st) {
     const int lds = 2 * 56 * SUB + 6 * (128 * 32 * 2);   // two halo buffers of 56 pieces, weight ring of 6 slices
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_halo<128, MASK>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_halo<128, MASK, LGTW>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 lds) != hipSuccess)
             return PP_ERR_HIP;
         attr_done = true;
@@ -1003,8 +1037,19 @@ int launch_halo_mask(const ConvParams &p, const HaloParams &g, hipStream_t st) {
         const float f = 0.5f * (rounds < 32.f ? rounds / 32.f : 1.f);
         q.stagger = grid.x < ids ? (int)(f * (float)(p.C / 32 * 9) * 1500.f / 8128.f + 0.5f) : 0;
     }
-    hipLaunchKernelGGL((k_conv3x3_halo<128, MASK>), grid, dim3(NTHREADS), lds, st, q, g);
+    hipLaunchKernelGGL((k_conv3x3_halo<128, MASK, LGTW>), grid, dim3(NTHREADS), lds, st, q, g);
     return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
+}
+
+template <int MASK>
+int launch_halo_mask(const ConvParams &p, const HaloParams &g, hipStream_t st) {
+    if (g.lgTW == 7) return launch_halo_inst<MASK, 7>(p, g, st);
+    if (MASK == 0) {   // the ablated instances exist for the 128-wide tile only
+        if (g.lgTW == 6) return launch_halo_inst<0, 6>(p, g, st);
+        if (g.lgTW == 5) return launch_halo_inst<0, 5>(p, g, st);
+        if (g.lgTW == 4) return launch_halo_inst<0, 4>(p, g, st);
+    }
+    return PP_ERR_UNSUPPORTED;
 }
 
 int launch_halo(const ConvParams &p, const HaloParams &g, hipStream_t st) {
