@@ -37,12 +37,14 @@ constexpr int NTHREADS = 512;
 constexpr int SUB = 1024;    // bytes of one LDS sub-tile: 16 rows x 32 halves
 
 struct ConvParams {
-    const _Float16 *x, *w, *bias, *extra;
+    const _Float16 *x, *w, *bias, *extra, *extra2;   // extra2: a second tensor added after the activation (mode 3; 3x3 halo kernel only)
     _Float16 *y;
     const void *zero;  // >= 16 zero bytes: source of every tap that falls outside the image
     int N, H, W, C, K, R, pad, dil, Ho, Wo;
     long M;            // N * Ho * Wo
-    int mode;          // 0 none, 1 extra added before the activation, 2 after
+    int mode;          // 0 none, 1 extra added before the activation, 2 after, 3 extra AND extra2 after
+    int up;            // 1: x is the input at HALF resolution (N x H/2 x W/2 x C); the kernel reads pixel (y >> 1, x >> 1): the x2
+                       // nearest upsample in front of the convolution costs no pass of its own (3x3 halo kernel only)
     float slope;
     int stagger;       // persistent 3x3 kernel: start delay of the last workgroup of an XCD, in units of s_sleep(127) (~8100 cycles)
     int dbg;           // ablation switches (POSEPAF_CONV_DBG, diagnostics only): 1 no DMA in the loop, 2 no MFMA, 4 no fragment
@@ -94,8 +96,9 @@ __device__ __forceinline__ void epilogue_body(const float4_t (&acc)[PT][CT], con
             const long m = pixel_of(i);
             if (m >= 0) {
                 const long o = m * p.K + co;
-                half8_t ev = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+                half8_t ev = half8_t{0, 0, 0, 0, 0, 0, 0, 0}, ev2 = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
                 if (MODE) ev = *reinterpret_cast<const half8_t *>(p.extra + o);
+                if (MODE == 3) ev2 = *reinterpret_cast<const half8_t *>(p.extra2 + o);
                 half8_t out;
 #pragma unroll
                 for (int e = 0; e < 4; e++) {   // two channels at a time: v_pk_add_f32 / v_pk_mul_f32
@@ -105,6 +108,10 @@ __device__ __forceinline__ void epilogue_body(const float4_t (&acc)[PT][CT], con
                     const float2_t u = t * slope2;   // LeakyReLU for 0 <= slope <= 1 (checked by the launcher); slope 1: none
                     t = float2_t{fmaxf(t[0], u[0]), fmaxf(t[1], u[1])};
                     if (MODE == 2) t += x;
+                    // mode 3 = the three-way add (k_add3) of the fp16 convolution output it replaces: the activation is rounded
+                    // to binary16 first, the sum of the three is formed in fp32 and rounded once
+                    if (MODE == 3)
+                        t = float2_t{(float)(_Float16)t[0], (float)(_Float16)t[1]} + x + float2_t{(float)ev2[2 * e], (float)ev2[2 * e + 1]};
                     out[2 * e] = (_Float16)t[0];
                     out[2 * e + 1] = (_Float16)t[1];
                 }
@@ -120,7 +127,8 @@ __device__ __forceinline__ void epilogue_store(const float4_t (&acc)[PT][CT], co
     // the residual mode is wave-uniform: three bodies, one scalar branch, no per-element selects
     if (p.mode == 0) epilogue_body<0, PT, CT>(acc, p, lane, nbase, pixel_of, do_store);
     else if (p.mode == 1) epilogue_body<1, PT, CT>(acc, p, lane, nbase, pixel_of, do_store);
-    else epilogue_body<2, PT, CT>(acc, p, lane, nbase, pixel_of, do_store);
+    else if (p.mode == 2) epilogue_body<2, PT, CT>(acc, p, lane, nbase, pixel_of, do_store);
+    else epilogue_body<3, PT, CT>(acc, p, lane, nbase, pixel_of, do_store);
 }
 
 // DIAGNOSTIC (MASK bit 64 of k_conv3x3_halo): the epilogue's arithmetic and store COUNT with every store instruction covering
@@ -382,7 +390,8 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
         ty0 = (tile / hp.tiles_x) * TH;
         tx0 = (tile - (tile / hp.tiles_x) * hp.tiles_x) * TW;
         n0 = ctile * BN;
-        xb = reinterpret_cast<const char *>(p.x) + (long)n_img * p.H * p.W * p.C * 2;   // this image
+        const int sw_ = p.up ? p.W >> 1 : p.W;                                       // source row length in pixels
+        xb = reinterpret_cast<const char *>(p.x) + (long)n_img * (p.up ? p.H >> 1 : p.H) * sw_ * p.C * 2;   // this image
         int ln = lane;
         asm volatile("" : "+v"(ln));   // recomputed per tile: hoisted, the per-piece halo coordinates would sit in 20 registers
 #pragma unroll
@@ -394,7 +403,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
             const int hy = hpix / HWp, hx = hpix - hy * HWp;
             const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
             const bool ok = hpix < NHALO && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            hsrc[t] = ok ? ((iy * p.W + ix) * p.C * 2 + chunk * 16) : -1;
+            hsrc[t] = ok ? (((iy >> p.up) * sw_ + (ix >> p.up)) * p.C * 2 + chunk * 16) : -1;
         }
         const int b = ln * 16;
         const int bs = b ^ (((b >> 9) & 1) << 5);
@@ -1116,11 +1125,15 @@ PP_API int pp_conv_debug_clock(double *out, int nwg) {
 
 PP_API int pp_conv_own_supported(int c_in, int c_out, int ksize) { return (c_in % 32 == 0 && c_out % 64 == 0 && ksize >= 1 && ksize <= 7) ? 1 : 0; }
 
-PP_API int pp_conv_own_f16(const void *x, const void *w, const void *bias, const void *extra, void *y, int n, int h, int wd, int c_in,
-                    int c_out, int ksize, int pad, int dilation, int extra_mode, float slope, int bn, void *stream) {
+PP_API int pp_conv_own_ex_f16(const void *x, const void *w, const void *bias, const void *extra, const void *extra2, void *y, int n, int h,
+                       int wd, int c_in, int c_out, int ksize, int pad, int dilation, int extra_mode, float slope, int bn, int upsampled_input,
+                       void *stream) {
     if (!x || !w || !bias || !y || n <= 0 || h <= 0 || wd <= 0 || ksize <= 0 || pad < 0 || dilation <= 0 || extra_mode < 0 ||
-        extra_mode > 2 || (extra_mode != 0) != (extra != nullptr))
+        extra_mode > 3 || (extra_mode != 0) != (extra != nullptr) || (extra_mode == 3) != (extra2 != nullptr) ||
+        (upsampled_input != 0 && upsampled_input != 1) || (reinterpret_cast<uintptr_t>(extra2) & 15))
         return PP_ERR_BAD_ARG;
+    if ((upsampled_input || extra_mode == 3) && bn != 512) return PP_ERR_UNSUPPORTED;   // the 8-wave 3x3 halo kernel only
+    if (upsampled_input && ((h | wd) & 1)) return PP_ERR_BAD_ARG;
     if (!pp_conv_own_supported(c_in, c_out, ksize)) return PP_ERR_UNSUPPORTED;
     if (!(slope >= 0.f && slope <= 1.f)) return PP_ERR_UNSUPPORTED;   // the epilogue's LeakyReLU is max(t, slope * t)
     const uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(bias) |
@@ -1137,6 +1150,8 @@ PP_API int pp_conv_own_f16(const void *x, const void *w, const void *bias, const
     p.w = static_cast<const _Float16 *>(w);
     p.bias = static_cast<const _Float16 *>(bias);
     p.extra = static_cast<const _Float16 *>(extra);
+    p.extra2 = static_cast<const _Float16 *>(extra2);
+    p.up = upsampled_input;
     p.y = static_cast<_Float16 *>(y);
     p.zero = g_zero_page;
     p.N = n; p.H = h; p.W = wd; p.C = c_in; p.K = c_out; p.R = ksize; p.pad = pad; p.dil = dilation; p.Ho = ho; p.Wo = wo;
@@ -1159,6 +1174,12 @@ PP_API int pp_conv_own_f16(const void *x, const void *w, const void *bias, const
         case 128: return launch<128>(p, st);
         default: return launch<64>(p, st);
     }
+}
+
+PP_API int pp_conv_own_f16(const void *x, const void *w, const void *bias, const void *extra, void *y, int n, int h, int wd, int c_in,
+                    int c_out, int ksize, int pad, int dilation, int extra_mode, float slope, int bn, void *stream) {
+    if (extra_mode > 2) return PP_ERR_BAD_ARG;
+    return pp_conv_own_ex_f16(x, w, bias, extra, nullptr, y, n, h, wd, c_in, c_out, ksize, pad, dilation, extra_mode, slope, bn, 0, stream);
 }
 
 }  // extern "C"

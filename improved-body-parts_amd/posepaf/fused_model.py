@@ -243,6 +243,62 @@ class FConv(nn.Module):
         _conv_timing[key] = times
         return best
 
+    # ---- x2 nearest upsample in front, up to two tensors added behind: one launch of the 3x3 halo kernel (pp_conv_own_ex_f16)
+    def forward_up2(self, low, post, post2=None):
+        """act(conv(upsample2(low)) + bias) + post (+ post2).  The upsample is read through the convolution's own halo loads
+        and the adds ride on its epilogue when that is faster than upsample2 -> convolution (-> add3), timed once per shape."""
+        from . import _lib
+        n, c, h, w = low.shape
+        k = self.weight.shape[0]
+        key = ("up2", n, c, h, w, k, post2 is not None, bool(self.act))
+        fused_ok = (USE_OWN_CONV and low.is_cuda and low.dtype == torch.float16 and self.stride == (1, 1)
+                    and tuple(self.weight.shape[2:]) == (3, 3) and self.padding == (1, 1) and self.dilation == (1, 1))
+
+        def separate():
+            if post2 is None:
+                return self(upsample2(low), post=post)
+            return add3(self(upsample2(low)), post, post2)   # the conv runs without the extra read, ONE pass adds the three
+
+        def fused():
+            x = _cl(low)
+            if not self.weight.is_contiguous(memory_format=torch.channels_last):
+                self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
+            y = torch.empty((n, k, 2 * h, 2 * w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            e1, e2 = _cl(post), (_cl(post2) if post2 is not None else None)
+            rc = _lib.load().pp_conv_own_ex_f16(_ptr(x), _ptr(self.weight), _ptr(self.bias), _ptr(e1), _ptr(e2), _ptr(y), n, 2 * h, 2 * w,
+                                                c, k, 3, 1, 1, 3 if post2 is not None else 2, LEAK if self.act else 1.0, 512, 1, _stream(x))
+            return y if rc == 0 else None
+
+        choice = _conv_choice.get(key) if fused_ok else 0
+        if choice is None:
+            if torch.cuda.is_current_stream_capturing():
+                return separate()
+            separate()                      # tunes the inner convolution's shape first
+            if fused() is None:
+                choice = 0
+            else:
+                def timed(fn):
+                    fn()
+                    torch.cuda.synchronize()
+                    ts = []
+                    for _ in range(_TUNE_REPS):
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        fn()
+                        e1.record()
+                        torch.cuda.synchronize()
+                        ts.append(e0.elapsed_time(e1))
+                    return sorted(ts)[len(ts) // 2]
+                t_sep, t_fused = timed(separate), timed(fused)
+                _conv_timing[key] = {"separate": t_sep, "fused": t_fused}
+                choice = 1 if t_fused < t_sep else 0
+            _conv_choice[key] = choice
+        if choice:
+            y = fused()
+            if y is not None:
+                return y
+        return separate()
+
     def forward(self, x, res=None, post=None):
         """act(conv(x) + bias (+ res)) (+ post)"""
         if self._fused_eligible(x, res, post):
@@ -308,9 +364,8 @@ class FHourglass(nn.Module):
         low = lv[1](maxpool2(x))
         low = lv[4](low) if i == self.depth - 1 else self._level(i + 1, low, coarse)
         coarse.append(low)
-        if cache0 is not None:   # top level of stages 2..: up1 + up2 + cache in ONE pass (the conv runs without the extra read)
-            return add3(lv[3](upsample2(lv[2](low))), up1, cache0)
-        return lv[3](upsample2(lv[2](low)), post=up1)  # up1 + act(conv(up2) + b): the add rides on the epilogue
+        # up1 + act(conv(upsample(low)) + b) (+ cache at the top level of stages 2..): one launch when the halo kernel takes it
+        return lv[3].forward_up2(lv[2](low), up1, cache0)
 
     def forward(self, x, cache0=None):
         """-> [top (+ cache0 when given), coarse levels...]"""

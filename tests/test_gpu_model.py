@@ -310,6 +310,91 @@ def test_halo_tile_3x3_convolution_matches_torch(shape):
                              0, 0.01, 512, stream) == -6
 
 
+@pytest.mark.parametrize("shape", [
+    # n, c_in, c_out, h_low, w_low: the convolution runs at (2 h_low, 2 w_low)
+    (2, 64, 128, 16, 16),       # 32-wide tiles
+    (1, 128, 256, 8, 64),       # 128-wide tiles, two output-channel tiles
+    (3, 32, 128, 32, 32),       # 64-wide tiles, one channel block
+])
+def test_halo_kernel_upsampled_input_and_two_post_adds(shape):
+    """pp_conv_own_ex_f16: the x2 nearest upsample (models/layers_transposed.py:212, :272) read through the 3x3 kernel's halo loads
+    (upsampled_input = 1) must equal the convolution of the materialised upsample BIT FOR BIT (same kernel, same operands in
+    LDS), and extra_mode 3 must equal fp16(act) + extra + extra2 summed in fp32 and rounded once (what the three-way add
+    kernel does with the fp16 convolution output)."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from posepaf import _lib
+    L = _lib.load()
+    n, ci, co, hl, wl = shape
+    h, w = 2 * hl, 2 * wl
+    g = torch.Generator(device="cpu").manual_seed(29)
+    low = torch.randn(n, ci, hl, wl, generator=g).cuda().half().contiguous(memory_format=torch.channels_last)
+    up = F.interpolate(low, scale_factor=2, mode="nearest").contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(co, ci, 3, 3, generator=g) / (ci * 9) ** 0.5).cuda().half().contiguous(memory_format=torch.channels_last)
+    b = torch.randn(co, generator=g).cuda().half()
+    e1 = torch.randn(n, co, h, w, generator=g).cuda().half().contiguous(memory_format=torch.channels_last)
+    e2 = torch.randn(n, co, h, w, generator=g).cuda().half().contiguous(memory_format=torch.channels_last)
+    vp = C.c_void_p
+    stream = vp(torch.cuda.current_stream().cuda_stream)
+
+    def run(x, mode, upflag, variant=512):
+        y = torch.full((n, co, h, w), float("nan"), dtype=torch.float16, device="cuda").contiguous(memory_format=torch.channels_last)
+        rc = L.pp_conv_own_ex_f16(vp(x.data_ptr()), vp(wt.data_ptr()), vp(b.data_ptr()), vp(e1.data_ptr()) if mode else None,
+                                  vp(e2.data_ptr()) if mode == 3 else None, vp(y.data_ptr()), n, h, w, ci, co, 3, 1, 1, mode, 0.01,
+                                  variant, upflag, stream)
+        torch.cuda.synchronize()
+        return rc, y
+
+    for mode in (0, 2, 3):
+        rc_a, y_up = run(low, mode, 1)
+        rc_b, y_mat = run(up, mode, 0)
+        assert rc_a == 0 and rc_b == 0, (mode, rc_a, rc_b)
+        assert torch.isfinite(y_up).all()
+        assert torch.equal(y_up, y_mat), (shape, mode, (y_up.float() - y_mat.float()).abs().max().item())
+    # mode 3 against its definition, built from the mode-0 output of the same kernel
+    _, y0 = run(up, 0, 0)
+    _, y3 = run(up, 3, 0)
+    assert torch.equal(y3, (y0.float() + e1.float() + e2.float()).half())
+    # and against torch in fp32, with the tolerance of the other convolution tests
+    ref = F.leaky_relu(F.conv2d(up.float(), wt.float(), b.float(), 1, 1, 1), 0.01) + e1.float() + e2.float()
+    assert (y3.float() - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
+    # refused where the extension does not exist: other kernels, odd sizes, inconsistent pointers
+    assert run(low, 2, 1, variant=256)[0] == -6 and run(low, 3, 0, variant=0)[0] == -6
+    y = torch.empty((n, co, h, w), dtype=torch.float16, device="cuda").contiguous(memory_format=torch.channels_last)
+    assert L.pp_conv_own_ex_f16(vp(low.data_ptr()), vp(wt.data_ptr()), vp(b.data_ptr()), vp(e1.data_ptr()), None, vp(y.data_ptr()),
+                                n, h, w, ci, co, 3, 1, 1, 3, 0.01, 512, 1, stream) == -2      # mode 3 without extra2: PP_ERR_BAD_ARG
+    assert L.pp_conv_own_f16(vp(up.data_ptr()), vp(wt.data_ptr()), vp(b.data_ptr()), vp(e1.data_ptr()), vp(y.data_ptr()),
+                             n, h, w, ci, co, 3, 1, 1, 3, 0.01, 512, stream) == -2
+
+
+def test_fused_model_upsample_convolution_paths_agree():
+    """FConv.forward_up2 (posepaf/fused_model.py): upsample -> convolution -> add(s) as separate launches and as ONE launch of
+    the halo kernel give identical tensors, with one and with two added tensors; the hourglass uses whichever is faster."""
+    from posepaf import fused_model as fm
+    torch.manual_seed(5)
+    conv = torch.nn.Conv2d(128, 128, 3, 1, 1, bias=False)
+    bn = torch.nn.BatchNorm2d(128)
+    bn.running_mean.normal_(0, 0.1)
+    bn.running_var.uniform_(0.5, 1.5)
+    f = fm.FConv(conv, bn.eval(), True).cuda().half()
+    low = torch.randn(2, 128, 32, 32, device="cuda").half().contiguous(memory_format=torch.channels_last)
+    p1 = torch.randn(2, 128, 64, 64, device="cuda").half().contiguous(memory_format=torch.channels_last)
+    p2 = torch.randn(2, 128, 64, 64, device="cuda").half().contiguous(memory_format=torch.channels_last)
+    for post2 in (None, p2):
+        sep = f(fm.upsample2(low), post=p1) if post2 is None else fm.add3(f(fm.upsample2(low)), p1, post2)
+        key = ("up2", 2, 128, 32, 32, 128, post2 is not None, True)
+        for choice in (0, 1):
+            fm._conv_choice[key] = choice
+            y = f.forward_up2(low, p1, post2)
+            # the inner convolution of the separate path may run on another tile configuration than the halo kernel: same
+            # operands, another summation order -> equal to within one binary16 rounding of the accumulator
+            assert (y.float() - sep.float()).abs().max().item() <= 2e-3 * max(1.0, sep.float().abs().max().item()), (post2 is None, choice)
+        fm._conv_choice.pop(key)
+        y = f.forward_up2(low, p1, post2)     # timed choice
+        assert key in fm._conv_choice and fm._conv_choice[key] in (0, 1)
+        assert (y.float() - sep.float()).abs().max().item() <= 2e-3 * max(1.0, sep.float().abs().max().item())
+
+
 def test_evaluate_two_ranks_on_one_gpu_gloo_rehearsal(tmp_path):
     """BASELINE configs[3]'s control flow on hardware: `evaluate.py --gpus 2` launches its own two ranks (one GPU shared, record
     exchange over gloo: POSEPAF_DIST_BACKEND=gloo), images sharded i mod 2, records gathered and re-interleaved into image
