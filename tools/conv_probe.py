@@ -20,7 +20,10 @@ with torch.no_grad():
     model(x)
 torch.cuda.synchronize()
 rows = []
+up2 = {k_: v for k_, v in fm._conv_timing.items() if k_[0] == "up2"}   # upsample -> 3x3 -> add(s): separate launches vs one (forward_up2)
 for key, times in fm._conv_timing.items():
+    if key[0] == "up2":
+        continue
     n, c, h, w, k, r, pad, dil, mode, act = key
     calls = fm._conv_calls.get(key, 0)
     best = fm._conv_choice[key]
@@ -38,3 +41,8 @@ print(f"sum over tuned shapes: {tot:.2f} ms per forward")
 print("all configurations, ms (top 8 shapes):")
 for tt, key, calls, best, t, tm, tf, gb in rows[:8]:
     print(key, {k: round(v, 3) for k, v in fm._conv_timing[key].items()})
+print("upsample x2 -> 3x3 convolution -> add(s): separate launches vs one launch of the halo kernel, ms")
+for key, t in up2.items():
+    _, n, c, h, w, k, two, act = key
+    print(f"  {c:4d}->{k:4d} from {h}x{w} ({'two adds' if two else 'one add'}): separate {t['separate']:.3f}  fused {t['fused']:.3f}  "
+          f"chosen {'fused' if fm._conv_choice[key] else 'separate'}")
