@@ -375,12 +375,14 @@ class GpuEngine:
                 from posepaf.fused_model import conv_choices
                 ch = conv_choices()
                 up2 = {k: v for k, v in ch.items() if k[0] == "up2"}     # upsample -> 3x3 -> add(s): 1 = one launch of the halo kernel
-                ch = {k: v for k, v in ch.items() if k[0] != "up2"}
+                dual = {k: v for k, v in ch.items() if k[0] == "dual"}   # convolution with a second output y + other: 0 = separate add
+                ch = {k: v for k, v in ch.items() if k[0] not in ("up2", "dual")}
                 out["conv_layers"] = {"shapes_own_kernel": sum(1 for v in ch.values() if v >= 100),
                                       "shapes_ck_template_kernel": sum(1 for v in ch.values() if 0 <= v < 100),
                                       "shapes_miopen_plus_epilogue": sum(1 for v in ch.values() if v < 0),
                                       "upsample_conv_add_sites_fused": sum(1 for v in up2.values() if v),
-                                      "upsample_conv_add_sites_separate": sum(1 for v in up2.values() if not v)}
+                                      "upsample_conv_add_sites_separate": sum(1 for v in up2.values() if not v),
+                                      "two_output_conv_sites_fused": sum(1 for v in dual.values() if v)}
         return out
 
 

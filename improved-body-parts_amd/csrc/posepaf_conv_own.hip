@@ -38,11 +38,12 @@ constexpr int SUB = 1024;    // bytes of one LDS sub-tile: 16 rows x 32 halves
 
 struct ConvParams {
     const _Float16 *x, *w, *bias, *extra, *extra2;   // extra2: a second tensor added after the activation (mode 3; 3x3 halo kernel only)
-    _Float16 *y;
+    _Float16 *y, *y2;  // y2: second output of mode 4
     const void *zero;  // >= 16 zero bytes: source of every tap that falls outside the image
     int N, H, W, C, K, R, pad, dil, Ho, Wo;
     long M;            // N * Ho * Wo
-    int mode;          // 0 none, 1 extra added before the activation, 2 after, 3 extra AND extra2 after
+    int mode;          // 0 none, 1 extra added before the activation, 2 after, 3 extra AND extra2 after (3x3 halo kernel),
+                       // 4 = mode 1 plus a SECOND OUTPUT y2 = y + extra2 (every kernel)
     int up;            // 1: x is the input at HALF resolution (N x H/2 x W/2 x C); the kernel reads pixel (y >> 1, x >> 1): the x2
                        // nearest upsample in front of the convolution costs no pass of its own (3x3 halo kernel only)
     float slope;
@@ -98,13 +99,13 @@ __device__ __forceinline__ void epilogue_body(const float4_t (&acc)[PT][CT], con
                 const long o = m * p.K + co;
                 half8_t ev = half8_t{0, 0, 0, 0, 0, 0, 0, 0}, ev2 = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
                 if (MODE) ev = *reinterpret_cast<const half8_t *>(p.extra + o);
-                if (MODE == 3) ev2 = *reinterpret_cast<const half8_t *>(p.extra2 + o);
-                half8_t out;
+                if (MODE >= 3) ev2 = *reinterpret_cast<const half8_t *>(p.extra2 + o);
+                half8_t out, out2;
 #pragma unroll
                 for (int e = 0; e < 4; e++) {   // two channels at a time: v_pk_add_f32 / v_pk_mul_f32
                     float2_t t = float2_t{v[2 * e], v[2 * e + 1]} + b2[e];
                     const float2_t x = float2_t{(float)ev[2 * e], (float)ev[2 * e + 1]};
-                    if (MODE == 1) t += x;
+                    if (MODE == 1 || MODE == 4) t += x;
                     const float2_t u = t * slope2;   // LeakyReLU for 0 <= slope <= 1 (checked by the launcher); slope 1: none
                     t = float2_t{fmaxf(t[0], u[0]), fmaxf(t[1], u[1])};
                     if (MODE == 2) t += x;
@@ -114,8 +115,13 @@ __device__ __forceinline__ void epilogue_body(const float4_t (&acc)[PT][CT], con
                         t = float2_t{(float)(_Float16)t[0], (float)(_Float16)t[1]} + x + float2_t{(float)ev2[2 * e], (float)ev2[2 * e + 1]};
                     out[2 * e] = (_Float16)t[0];
                     out[2 * e + 1] = (_Float16)t[1];
+                    if (MODE == 4) {   // the tensor add y + extra2 of the two binary16 tensors: exact sum, rounded once
+                        out2[2 * e] = (_Float16)((float)out[2 * e] + (float)ev2[2 * e]);
+                        out2[2 * e + 1] = (_Float16)((float)out[2 * e + 1] + (float)ev2[2 * e + 1]);
+                    }
                 }
                 if (do_store) *reinterpret_cast<half8_t *>(p.y + o) = out;
+                if (MODE == 4 && do_store) *reinterpret_cast<half8_t *>(p.y2 + o) = out2;
             }
         }
     }
@@ -128,7 +134,8 @@ __device__ __forceinline__ void epilogue_store(const float4_t (&acc)[PT][CT], co
     if (p.mode == 0) epilogue_body<0, PT, CT>(acc, p, lane, nbase, pixel_of, do_store);
     else if (p.mode == 1) epilogue_body<1, PT, CT>(acc, p, lane, nbase, pixel_of, do_store);
     else if (p.mode == 2) epilogue_body<2, PT, CT>(acc, p, lane, nbase, pixel_of, do_store);
-    else epilogue_body<3, PT, CT>(acc, p, lane, nbase, pixel_of, do_store);
+    else if (p.mode == 3) epilogue_body<3, PT, CT>(acc, p, lane, nbase, pixel_of, do_store);
+    else epilogue_body<4, PT, CT>(acc, p, lane, nbase, pixel_of, do_store);
 }
 
 // DIAGNOSTIC (MASK bit 64 of k_conv3x3_halo): the epilogue's arithmetic and store COUNT with every store instruction covering
@@ -1125,14 +1132,16 @@ PP_API int pp_conv_debug_clock(double *out, int nwg) {
 
 PP_API int pp_conv_own_supported(int c_in, int c_out, int ksize) { return (c_in % 32 == 0 && c_out % 64 == 0 && ksize >= 1 && ksize <= 7) ? 1 : 0; }
 
-PP_API int pp_conv_own_ex_f16(const void *x, const void *w, const void *bias, const void *extra, const void *extra2, void *y, int n, int h,
-                       int wd, int c_in, int c_out, int ksize, int pad, int dilation, int extra_mode, float slope, int bn, int upsampled_input,
-                       void *stream) {
+PP_API int pp_conv_own_ex_f16(const void *x, const void *w, const void *bias, const void *extra, const void *extra2, void *y, void *y2,
+                       int n, int h, int wd, int c_in, int c_out, int ksize, int pad, int dilation, int extra_mode, float slope, int bn,
+                       int upsampled_input, void *stream) {
     if (!x || !w || !bias || !y || n <= 0 || h <= 0 || wd <= 0 || ksize <= 0 || pad < 0 || dilation <= 0 || extra_mode < 0 ||
-        extra_mode > 3 || (extra_mode != 0) != (extra != nullptr) || (extra_mode == 3) != (extra2 != nullptr) ||
-        (upsampled_input != 0 && upsampled_input != 1) || (reinterpret_cast<uintptr_t>(extra2) & 15))
+        extra_mode > 4 || (extra_mode != 0) != (extra != nullptr) || (extra_mode >= 3) != (extra2 != nullptr) ||
+        (extra_mode == 4) != (y2 != nullptr) || (upsampled_input != 0 && upsampled_input != 1) ||
+        ((reinterpret_cast<uintptr_t>(extra2) | reinterpret_cast<uintptr_t>(y2)) & 15))
         return PP_ERR_BAD_ARG;
     if ((upsampled_input || extra_mode == 3) && bn != 512) return PP_ERR_UNSUPPORTED;   // the 8-wave 3x3 halo kernel only
+    if (extra_mode == 4 && (bn == 514 || bn == 516)) return PP_ERR_UNSUPPORTED;
     if (upsampled_input && ((h | wd) & 1)) return PP_ERR_BAD_ARG;
     if (!pp_conv_own_supported(c_in, c_out, ksize)) return PP_ERR_UNSUPPORTED;
     if (!(slope >= 0.f && slope <= 1.f)) return PP_ERR_UNSUPPORTED;   // the epilogue's LeakyReLU is max(t, slope * t)
@@ -1153,6 +1162,7 @@ PP_API int pp_conv_own_ex_f16(const void *x, const void *w, const void *bias, co
     p.extra2 = static_cast<const _Float16 *>(extra2);
     p.up = upsampled_input;
     p.y = static_cast<_Float16 *>(y);
+    p.y2 = static_cast<_Float16 *>(y2);
     p.zero = g_zero_page;
     p.N = n; p.H = h; p.W = wd; p.C = c_in; p.K = c_out; p.R = ksize; p.pad = pad; p.dil = dilation; p.Ho = ho; p.Wo = wo;
     p.M = (long)n * ho * wo;
@@ -1179,7 +1189,8 @@ PP_API int pp_conv_own_ex_f16(const void *x, const void *w, const void *bias, co
 PP_API int pp_conv_own_f16(const void *x, const void *w, const void *bias, const void *extra, void *y, int n, int h, int wd, int c_in,
                     int c_out, int ksize, int pad, int dilation, int extra_mode, float slope, int bn, void *stream) {
     if (extra_mode > 2) return PP_ERR_BAD_ARG;
-    return pp_conv_own_ex_f16(x, w, bias, extra, nullptr, y, n, h, wd, c_in, c_out, ksize, pad, dilation, extra_mode, slope, bn, 0, stream);
+    return pp_conv_own_ex_f16(x, w, bias, extra, nullptr, y, nullptr, n, h, wd, c_in, c_out, ksize, pad, dilation, extra_mode, slope, bn, 0,
+                              stream);
 }
 
 }  // extern "C"

@@ -91,7 +91,7 @@ def load():
     L.pp_conv_num_configs.argtypes = []
     L.pp_conv_f16.argtypes = [vp, vp, vp, vp, vp] + [C.c_int] * 9 + [C.c_float, C.c_int, vp]
     L.pp_conv_own_f16.argtypes = [vp, vp, vp, vp, vp] + [C.c_int] * 9 + [C.c_float, C.c_int, vp]
-    L.pp_conv_own_ex_f16.argtypes = [vp, vp, vp, vp, vp, vp] + [C.c_int] * 9 + [C.c_float, C.c_int, C.c_int, vp]
+    L.pp_conv_own_ex_f16.argtypes = [vp, vp, vp, vp, vp, vp, vp] + [C.c_int] * 9 + [C.c_float, C.c_int, C.c_int, vp]
     L.pp_conv_own_supported.argtypes = [C.c_int, C.c_int, C.c_int]
     L.pp_debug_set_stamps.argtypes = [vp]
     L.pp_debug_set_mode.argtypes = [vp, C.c_int]

@@ -265,7 +265,7 @@ class FConv(nn.Module):
                 self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
             y = torch.empty((n, k, 2 * h, 2 * w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
             e1, e2 = _cl(post), (_cl(post2) if post2 is not None else None)
-            rc = _lib.load().pp_conv_own_ex_f16(_ptr(x), _ptr(self.weight), _ptr(self.bias), _ptr(e1), _ptr(e2), _ptr(y), n, 2 * h, 2 * w,
+            rc = _lib.load().pp_conv_own_ex_f16(_ptr(x), _ptr(self.weight), _ptr(self.bias), _ptr(e1), _ptr(e2), _ptr(y), None, n, 2 * h, 2 * w,
                                                 c, k, 3, 1, 1, 3 if post2 is not None else 2, LEAK if self.act else 1.0, 512, 1, _stream(x))
             return y if rc == 0 else None
 
@@ -297,6 +297,66 @@ class FConv(nn.Module):
             y = fused()
             if y is not None:
                 return y
+        return separate()
+
+    # ---- two outputs: y = act(conv(x) + bias + res) and y + other, one launch of an own kernel (pp_conv_own_ex_f16 mode 4)
+    def forward_dual(self, x, res, other):
+        """-> (y, y + other) with y = act(conv(x) + bias + res).  One launch with two stores when that beats the fused
+        convolution followed by a tensor add, timed once per shape."""
+        from . import _lib
+        n, c, h, w = x.shape
+        k, r = self.weight.shape[0], self.weight.shape[2]
+        key = ("dual", n, c, h, w, k, r, self.padding[0], self.dilation[0], bool(self.act))
+        ok = (USE_OWN_CONV and x.is_cuda and x.dtype == torch.float16 and self.stride == (1, 1) and res is not None
+              and self.weight.shape[2] == self.weight.shape[3] and self.padding[0] == self.padding[1] and self.dilation[0] == self.dilation[1]
+              and 2 * self.padding[0] == self.dilation[0] * (r - 1) and _lib.load().pp_conv_own_supported(c, k, r))
+
+        def separate():
+            y = self(x, res)
+            return y, y + other
+
+        def fused(bn):
+            xx, rr, oo = _cl(x), _cl(res), _cl(other)
+            if not self.weight.is_contiguous(memory_format=torch.channels_last):
+                self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
+            y = torch.empty((n, k, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            y2 = torch.empty_like(y, memory_format=torch.channels_last)
+            rc = _lib.load().pp_conv_own_ex_f16(_ptr(xx), _ptr(self.weight), _ptr(self.bias), _ptr(rr), _ptr(oo), _ptr(y), _ptr(y2), n, h, w,
+                                                c, k, r, self.padding[0], self.dilation[0], 4, LEAK if self.act else 1.0, bn, 0, _stream(x))
+            return (y, y2) if rc == 0 else None
+
+        choice = _conv_choice.get(key) if ok else 0
+        if choice is None:
+            if torch.cuda.is_current_stream_capturing():
+                return separate()
+            separate()                      # tunes the plain convolution's shape first
+
+            def timed(fn):
+                fn()
+                torch.cuda.synchronize()
+                ts = []
+                for _ in range(_TUNE_REPS):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    fn()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ts.append(e0.elapsed_time(e1))
+                return sorted(ts)[len(ts) // 2]
+            times = {"separate": timed(separate)}
+            choice, best = 0, times["separate"]
+            for bn in (256, 128, 64, 512):
+                if k % (bn if bn != 512 else 128) or fused(bn) is None:
+                    continue
+                times[bn] = timed(lambda: fused(bn))
+                if times[bn] < best:
+                    choice, best = bn, times[bn]
+            _conv_timing[key] = times
+            _conv_choice[key] = choice
+        if choice:
+            out = fused(choice)
+            if out is not None:
+                return out
         return separate()
 
     def forward(self, x, res=None, post=None):
@@ -438,8 +498,9 @@ class FusedIMHN(nn.Module):
             preds = [self.head[t][s](feats[s]) for s in scales]
             if last:
                 return preds[0]
-            caches = [self.mfeat[t][s](feats[s], self.mpred[t][s].conv_only(preds[s])) for s in scales]
-            x = x + caches[0]
+            # cache_s = merge_feat(feat_s) + merge_pred(pred_s); x + cache_0 leaves the scale-0 convolution as a second output
+            c0, x = self.mfeat[t][0].forward_dual(feats[0], self.mpred[t][0].conv_only(preds[0]), x)
+            caches = [c0] + [self.mfeat[t][s](feats[s], self.mpred[t][s].conv_only(preds[s])) for s in scales if s > 0]
 
 
 class GraphedForward:

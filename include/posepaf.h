@@ -196,14 +196,18 @@ PP_API int pp_conv_debug_clock(double *out6, int nwg);
 PP_API int pp_conv_own_f16(const void *x, const void *w, const void *bias, const void *extra, void *y, int n, int h, int wd,
                            int c_in, int c_out, int ksize, int pad, int dilation, int extra_mode, float slope, int bn,
                            void *stream);
-/* The same with two extensions of the 3x3 / pad 1 halo-tile kernel (bn = 512 only, PP_ERR_UNSUPPORTED otherwise):
+/* The same with extensions.  For the 3x3 / pad 1 halo-tile kernel (bn = 512 only, PP_ERR_UNSUPPORTED otherwise):
  *  - upsampled_input = 1: x is (n, h/2, wd/2, c_in) and stands for its x2 nearest-neighbour upsample (h, wd even) -- the
  *    `self.upsample(down3)` of models/layers_transposed.py:272 (nn.Upsample, :212) without materialising the upsample;
  *  - extra_mode = 3: y = fp16(act(conv + bias)) + extra + extra2 (fp32 sum, rounded once) -- the hourglass' `up1 + up2`
- *    and the stage's feature-cache add (models/posenet.py:104-106) inside the convolution's epilogue. */
-PP_API int pp_conv_own_ex_f16(const void *x, const void *w, const void *bias, const void *extra, const void *extra2, void *y, int n, int h,
-                              int wd, int c_in, int c_out, int ksize, int pad, int dilation, int extra_mode, float slope, int bn,
-                              int upsampled_input, void *stream);
+ *    and the stage's feature-cache add (models/posenet.py:104-106) inside the convolution's epilogue.
+ * For every kernel (bn = 0 / 256 / 128 / 64 / 512):
+ *  - extra_mode = 4: y = act(conv + bias + extra) as in mode 1 and a SECOND OUTPUT y2 = y + extra2 (the sum of the two
+ *    binary16 tensors, rounded once) -- `cache = merge_preds(...) + merge_features(...)` and `x = x + cache`
+ *    (models/posenet.py:116-118) in one pass.  y2 is NULL in every other mode. */
+PP_API int pp_conv_own_ex_f16(const void *x, const void *w, const void *bias, const void *extra, const void *extra2, void *y, void *y2,
+                              int n, int h, int wd, int c_in, int c_out, int ksize, int pad, int dilation, int extra_mode, float slope,
+                              int bn, int upsampled_input, void *stream);
 
 /* A0 pre-processing (utils/parse_skeletons.py:52-73, utils/util.py:44-65) of a batch of equally sized BGR uint8 DEVICE
  * images (batch, h, w, 3): pad bottom/right to a multiple of pad_to with pad_value, divide by 255, and write each image

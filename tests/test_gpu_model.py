@@ -340,7 +340,7 @@ def test_halo_kernel_upsampled_input_and_two_post_adds(shape):
     def run(x, mode, upflag, variant=512):
         y = torch.full((n, co, h, w), float("nan"), dtype=torch.float16, device="cuda").contiguous(memory_format=torch.channels_last)
         rc = L.pp_conv_own_ex_f16(vp(x.data_ptr()), vp(wt.data_ptr()), vp(b.data_ptr()), vp(e1.data_ptr()) if mode else None,
-                                  vp(e2.data_ptr()) if mode == 3 else None, vp(y.data_ptr()), n, h, w, ci, co, 3, 1, 1, mode, 0.01,
+                                  vp(e2.data_ptr()) if mode == 3 else None, vp(y.data_ptr()), None, n, h, w, ci, co, 3, 1, 1, mode, 0.01,
                                   variant, upflag, stream)
         torch.cuda.synchronize()
         return rc, y
@@ -361,10 +361,58 @@ def test_halo_kernel_upsampled_input_and_two_post_adds(shape):
     # refused where the extension does not exist: other kernels, odd sizes, inconsistent pointers
     assert run(low, 2, 1, variant=256)[0] == -6 and run(low, 3, 0, variant=0)[0] == -6
     y = torch.empty((n, co, h, w), dtype=torch.float16, device="cuda").contiguous(memory_format=torch.channels_last)
-    assert L.pp_conv_own_ex_f16(vp(low.data_ptr()), vp(wt.data_ptr()), vp(b.data_ptr()), vp(e1.data_ptr()), None, vp(y.data_ptr()),
+    assert L.pp_conv_own_ex_f16(vp(low.data_ptr()), vp(wt.data_ptr()), vp(b.data_ptr()), vp(e1.data_ptr()), None, vp(y.data_ptr()), None,
                                 n, h, w, ci, co, 3, 1, 1, 3, 0.01, 512, 1, stream) == -2      # mode 3 without extra2: PP_ERR_BAD_ARG
     assert L.pp_conv_own_f16(vp(up.data_ptr()), vp(wt.data_ptr()), vp(b.data_ptr()), vp(e1.data_ptr()), vp(y.data_ptr()),
                              n, h, w, ci, co, 3, 1, 1, 3, 0.01, 512, stream) == -2
+
+
+def test_two_output_convolution_matches_convolution_plus_add():
+    """pp_conv_own_ex_f16 mode 4 (every own kernel): y must equal the same kernel's mode-1 output bit for bit and y2 must be
+    the binary16 sum y + extra2 (models/posenet.py:116-118: cache and x + cache); FConv.forward_dual returns the same pair as
+    convolution followed by a tensor add."""
+    import ctypes as C
+    from posepaf import _lib, fused_model as fm
+    L = _lib.load()
+    vp = C.c_void_p
+    g = torch.Generator(device="cpu").manual_seed(31)
+    for (n, ci, co, h, w, k, pad), variants in [((2, 128, 256, 32, 32, 1, 0), (256, 128, 64, 0)), ((1, 64, 128, 16, 64, 3, 1), (128, 64, 512))]:
+        x = torch.randn(n, ci, h, w, generator=g).cuda().half().contiguous(memory_format=torch.channels_last)
+        wt = (torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5).cuda().half().contiguous(memory_format=torch.channels_last)
+        b = torch.randn(co, generator=g).cuda().half()
+        e1 = torch.randn(n, co, h, w, generator=g).cuda().half().contiguous(memory_format=torch.channels_last)
+        e2 = torch.randn(n, co, h, w, generator=g).cuda().half().contiguous(memory_format=torch.channels_last)
+        stream = vp(torch.cuda.current_stream().cuda_stream)
+        for bn in variants:
+            y1 = torch.empty((n, co, h, w), dtype=torch.float16, device="cuda").contiguous(memory_format=torch.channels_last)
+            assert L.pp_conv_own_f16(vp(x.data_ptr()), vp(wt.data_ptr()), vp(b.data_ptr()), vp(e1.data_ptr()), vp(y1.data_ptr()),
+                                     n, h, w, ci, co, k, pad, 1, 1, 0.01, bn, stream) == 0
+            y = torch.full_like(y1, float("nan"))
+            y2 = torch.full_like(y1, float("nan"))
+            assert L.pp_conv_own_ex_f16(vp(x.data_ptr()), vp(wt.data_ptr()), vp(b.data_ptr()), vp(e1.data_ptr()), vp(e2.data_ptr()),
+                                        vp(y.data_ptr()), vp(y2.data_ptr()), n, h, w, ci, co, k, pad, 1, 4, 0.01, bn, 0, stream) == 0
+            torch.cuda.synchronize()
+            assert torch.equal(y, y1), bn
+            assert torch.equal(y2, y1 + e2), bn
+        # missing second output / second operand: refused
+        assert L.pp_conv_own_ex_f16(vp(x.data_ptr()), vp(wt.data_ptr()), vp(b.data_ptr()), vp(e1.data_ptr()), vp(e2.data_ptr()),
+                                    vp(y.data_ptr()), None, n, h, w, ci, co, k, pad, 1, 4, 0.01, 0, 0, stream) == -2
+    torch.manual_seed(6)
+    f = fm.FConv(torch.nn.Conv2d(128, 256, 1, bias=True), None, False).cuda().half()
+    x = torch.randn(2, 128, 32, 32, device="cuda").half().contiguous(memory_format=torch.channels_last)
+    res = torch.randn(2, 256, 32, 32, device="cuda").half().contiguous(memory_format=torch.channels_last)
+    other = torch.randn(2, 256, 32, 32, device="cuda").half().contiguous(memory_format=torch.channels_last)
+    ref = f(x, res)
+    key = ("dual", 2, 128, 32, 32, 256, 1, 0, 1, False)
+    for choice in (0, 256, 128):
+        fm._conv_choice[key] = choice
+        y, y2 = f.forward_dual(x, res, other)
+        tol = 2e-3 * max(1.0, ref.float().abs().max().item())
+        assert (y.float() - ref.float()).abs().max().item() <= tol, choice
+        assert torch.equal(y2, y + other), choice
+    fm._conv_choice.pop(key)
+    y, y2 = f.forward_dual(x, res, other)
+    assert key in fm._conv_choice and torch.equal(y2, y + other)
 
 
 def test_fused_model_upsample_convolution_paths_agree():

@@ -22,7 +22,7 @@ torch.cuda.synchronize()
 rows = []
 up2 = {k_: v for k_, v in fm._conv_timing.items() if k_[0] == "up2"}   # upsample -> 3x3 -> add(s): separate launches vs one (forward_up2)
 for key, times in fm._conv_timing.items():
-    if key[0] == "up2":
+    if key[0] in ("up2", "dual"):
         continue
     n, c, h, w, k, r, pad, dil, mode, act = key
     calls = fm._conv_calls.get(key, 0)
@@ -46,3 +46,7 @@ for key, t in up2.items():
     _, n, c, h, w, k, two, act = key
     print(f"  {c:4d}->{k:4d} from {h}x{w} ({'two adds' if two else 'one add'}): separate {t['separate']:.3f}  fused {t['fused']:.3f}  "
           f"chosen {'fused' if fm._conv_choice[key] else 'separate'}")
+print("convolution + second output (y, y + other): separate add vs one launch per own tile width, ms")
+for key, t in fm._conv_timing.items():
+    if key[0] == "dual":
+        print(" ", key[1:], {k_: round(v, 3) for k_, v in t.items()}, "chosen", fm._conv_choice[key] or "separate")
