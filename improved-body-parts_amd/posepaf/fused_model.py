@@ -37,6 +37,20 @@ _conv_calls: dict = {}    # shape key -> number of forward() calls since import 
 _TUNE_REPS = 5
 
 
+_progress = None   # callable(str) or None: one line per tuned layer shape (bench.py prints them to stderr: a silent warm-up of
+                   # several minutes looks like a hang to a job supervisor)
+
+
+def set_progress(fn) -> None:
+    global _progress
+    _progress = fn
+
+
+def _note(key, choice) -> None:
+    if _progress is not None:
+        _progress(f"tuned shape {len(_conv_choice)}: {key} -> {choice}")
+
+
 def conv_choices() -> dict:
     """The per-shape decisions taken so far (for bench.py / DESIGN.md)."""
     return dict(_conv_choice)
@@ -241,6 +255,7 @@ class FConv(nn.Module):
                 best, best_t = cfg, t
         _conv_choice[key] = best
         _conv_timing[key] = times
+        _note(key, best)
         return best
 
     # ---- x2 nearest upsample in front, up to two tensors added behind: one launch of the 3x3 halo kernel (pp_conv_own_ex_f16)
@@ -293,6 +308,7 @@ class FConv(nn.Module):
                 _conv_timing[key] = {"separate": t_sep, "fused": t_fused}
                 choice = 1 if t_fused < t_sep else 0
             _conv_choice[key] = choice
+            _note(key, choice)
         if choice:
             y = fused()
             if y is not None:
@@ -353,6 +369,7 @@ class FConv(nn.Module):
                     choice, best = bn, times[bn]
             _conv_timing[key] = times
             _conv_choice[key] = choice
+            _note(key, choice)
         if choice:
             out = fused(choice)
             if out is not None:
