@@ -327,8 +327,10 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_igemm(const ConvParams p) {
 // K-steps whose pixel fragments are read from the same halo at shifted pixel offsets.  Only the weights still stream per tap:
 // BN = 128 output channels x 32 halves = 8 KiB per phase, next to ~5.6 KiB of halo, instead of 32 KiB per phase above.
 // 8 waves as 4 (pixels) x 2 (channels), 128 x 64 outputs per wave (128 accumulator VGPRs), v_mfma_f32_16x16x32_f16 with the
-// weight fragment as A and the pixel fragment as B as above; same four-slot weight ring, counted vmcnt, raw barriers and
-// half-phase stagger between the two waves of each SIMD.
+// weight fragment as A and the pixel fragment as B as above; six-slot weight ring five slices ahead, counted vmcnt AND counted
+// lgkmcnt, one raw barrier per phase, the phase body placed by hand (see the main loop), persistent workgroups (one per CU),
+// the tile geometry a template parameter (LGTW = log2 of the tile width: 7, 6, 5, 4 for image widths >= 128, 64, 32, 16).
+// Measured (tools/conv_ablate.py, 256 -> 256 @ 128 x 128, N = 128): 2.13 ms = 1.16 PFLOP/s; SQ_LDS_BANK_CONFLICT = 0.
 constexpr int TP = 512;  // output pixels per workgroup
 
 struct HaloParams {
