@@ -1071,14 +1071,14 @@ int launch_halo_mask(const ConvParams &p, const HaloParams &g, hipStream_t st) {
 }
 
 int launch_halo(const ConvParams &p, const HaloParams &g, hipStream_t st) {
-    switch (p.dbg) {   // POSEPAF_CONV_DBG (diagnostics): compile-time ablated instances; 0 = the product
+    // POSEPAF_CONV_DBG (diagnostics): compile-time ablated instances; 0 = the product.  "No MFMA" exists only together with "no
+    // fragment reads" (6, 7): a hand-placed ds_read whose result nothing consumes may land in a register the compiler has re-used.
+    switch (p.dbg) {
         case 0: return launch_halo_mask<0>(p, g, st);
         case 1: return launch_halo_mask<1>(p, g, st);     // no DMA inside the loop
-        case 2: return launch_halo_mask<2>(p, g, st);     // no MFMA
         case 4: return launch_halo_mask<4>(p, g, st);     // no fragment reads
         case 6: return launch_halo_mask<6>(p, g, st);     // DMA + barriers only
         case 5: return launch_halo_mask<5>(p, g, st);     // MFMA + barriers only
-        case 3: return launch_halo_mask<3>(p, g, st);     // fragment reads + barriers only
         case 7: return launch_halo_mask<7>(p, g, st);     // barriers only
         case 15: return launch_halo_mask<15>(p, g, st);   // ... and no epilogue
         case 64: return launch_halo_mask<64>(p, g, st);   // full-line store pattern (wrong placement: timing only)

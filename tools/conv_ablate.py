@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Ablation of the halo-tile 3x3 kernel on the hot layer (256 -> 256 @ 128 x 128, batch 128): time with parts switched off
-(POSEPAF_CONV_DBG bits: 1 no DMA, 2 no MFMA, 4 no fragment reads, 8 no stores).  Run once per setting (the env is read once)."""
+(POSEPAF_CONV_DBG = 1 no DMA in the loop, 4 no fragment reads, 5 MFMA + barriers only, 6 DMA + barriers only, 7 barriers only, 15 ... and no epilogue stores, 64 / 71 full-line store pattern, 1024 (+4, +5, +128) in-kernel section stamps and clock).  Run once per setting (the env is read once)."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "improved-body-parts_amd")):
