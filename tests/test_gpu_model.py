@@ -270,6 +270,8 @@ def test_own_implicit_gemm_convolution_matches_torch(shape):
     (1, 256, 256, 16, 64),      # 8 x 64 tiles, two output-channel tiles, 8 channel blocks
     (1, 96, 128, 128, 128),     # 4 x 128 tiles (the hot layer's geometry), 3 channel blocks, 32 tiles
     (2, 32, 384, 8, 256),       # 256-wide image: two 4 x 128 tiles per row pair; one channel block (no halo prefetch)
+    (9, 64, 256, 64, 128),      # 288 workgroup ids on a 256-workgroup persistent grid: 32 workgroups walk two tiles
+    (131, 32, 128, 32, 32),     # 262 pixel tiles: 33 per XCD range with two padding ids, second tiles on 8 workgroups only
 ])
 def test_halo_tile_3x3_convolution_matches_torch(shape):
     """pp_conv_own_f16 with bn = 512: the 3x3 kernel that keeps the input halo of a 512-pixel tile in LDS and reads the nine
