@@ -674,310 +674,9 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
         for (int k = 0; k < 6; k++) g_conv_clk[blockIdx.x * 8 + k] = acc_t[k];
 }
 
-// ------------------------------------------------------------------------------------------------ 3x3 halo, 4 waves
-// The same tile (512 pixels x 128 channels), halo buffers and weight ring as k_conv3x3_halo, but ONE wave per SIMD with the whole
-// 512-entry register file: 256 x 64 outputs per wave (256 accumulator registers), and the fragments of phase p+1 are read
-// from LDS into a second register set BEFORE the 64 MFMAs of phase p are issued, so the matrix pipe never waits for a
-// SIMD partner's LOAD section -- the ablation of the 8-wave kernel shows that section (DMA issue + 12 ds_read_b128 + waits)
-// to be longer than the partner's 32 MFMAs.  20 fragment reads per 64 MFMAs (0.31 per MFMA instead of 0.375), one barrier per
-// phase, weights three phases ahead, counted vmcnt.
-template <bool ABLATE>
-__global__ __launch_bounds__(256) void k_conv3x3_halo4(const ConvParams p, const HaloParams hp) {
-    constexpr int BN = 128, WB = BN * 32 * 2;
-    constexpr int PT = 16, CT = 4;   // 256 pixels x 64 channels per wave
-    constexpr int NL = 4;            // DMA per wave and phase: 2 halo pieces (or dummies) + 2 weight sub-tiles
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int halo_bytes = hp.npieces * SUB;
-    unsigned char *s_halo = smem;
-    unsigned char *s_w = smem + 2 * halo_bytes;
-    unsigned char *s_dummy = s_w + 4 * WB;   // [4][1 KiB]
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int n_img = blockIdx.x / hp.tiles, tile = blockIdx.x - n_img * hp.tiles;
-    const int ty0 = (tile / hp.tiles_x) * hp.TH, tx0 = (tile - (tile / hp.tiles_x) * hp.tiles_x) * hp.TW;
-    const int n0 = blockIdx.y * BN;
-    const char *xb = reinterpret_cast<const char *>(p.x) + (long)n_img * p.H * p.W * p.C * 2;   // this image
-    const char *wb = reinterpret_cast<const char *>(p.w);
-    const char *zp = reinterpret_cast<const char *>(p.zero);
-
-    // halo pieces of this wave: (t, j) -> piece (2 t + j) * 4 + wave, t = tap 0..6, j = 0..1; 32-bit offsets inside the image
-    int hsrc[14];
-#pragma unroll
-    for (int q = 0; q < 14; q++) {
-        const int piece = q * 4 + wave;
-        const int phys = piece * SUB + lane * 16;
-        const int logical = phys ^ (((phys >> 8) & 1) << 5);
-        const int hpix = logical >> 6, chunk = (logical >> 4) & 3;
-        const int hy = hpix / hp.HWp, hx = hpix - hy * hp.HWp;
-        const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
-        const bool ok = piece < hp.npieces && hpix < hp.nhalo && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        hsrc[q] = ok ? ((iy * p.W + ix) * p.C * 2 + chunk * 16) : -1;
-    }
-    const int b = lane * 16;
-    const int bs = b ^ (((b >> 9) & 1) << 5);
-    const long wrow = 9L * p.C * 2;
-    long woff[2];
-#pragma unroll
-    for (int j = 0; j < 2; j++) woff[j] = (long)(n0 + (wave * 2 + j) * 16 + (bs >> 6)) * wrow + (bs & 63);
-
-    const int ncb = p.C / 32;
-    const int np = ncb * 9;
-    int st_cb = 0, st_tap = 0;
-    auto stage_w = [&](int slot) {
-        const long k = ((long)st_tap * p.C + (long)st_cb * 32) * 2;
-#pragma unroll
-        for (int j = 0; j < 2; j++) lds_dma16(wb + woff[j] + k, s_w + slot * WB + (wave * 2 + j) * SUB);
-        if (++st_tap == 9) {
-            st_tap = 0;
-            ++st_cb;
-        }
-    };
-    auto stage_halo = [&](int t, int cb, int buf) {
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int q = t * 2 + j;
-            if (t < 7 && q * 4 + wave < hp.npieces) {
-                int off = -1;
-#pragma unroll
-                for (int u = 0; u < 14; u++) off = q == u ? hsrc[u] : off;
-                const uintptr_t src = off >= 0 ? reinterpret_cast<uintptr_t>(xb) + (uintptr_t)((long)off + (long)cb * 64)
-                                               : reinterpret_cast<uintptr_t>(zp);
-                lds_dma16(reinterpret_cast<const void *>(src), s_halo + buf * halo_bytes + (q * 4 + wave) * SUB);
-            } else {
-                lds_dma16(zp, s_dummy + wave * SUB);
-            }
-        }
-    };
-
-    float4_t acc[PT][CT];
-#pragma unroll
-    for (int i = 0; i < PT; i++)
-#pragma unroll
-        for (int j = 0; j < CT; j++) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
-
-    const int wfrag = (lane & 15) * 64 + (((lane >> 4) * 16) ^ (((lane & 15) >> 3) << 5));
-    // pixel tile i of this wave starts at tile pixel wm * 256 + 16 i (a multiple of 16 <= TW): its halo offset relative to
-    // tile 0 is wave-uniform, so ONE vector register holds the lane part and the rest is scalar arithmetic
-    const int hb0 = (((wm * 256) >> hp.lgTW) * hp.HWp + (lane & 15)) * 64 + (lane >> 4) * 16;
-    auto read_frags = [&](int ph_, int cb_, int tap_, half8_t (&wf)[CT], half8_t (&xf)[PT]) {
-        const int r = tap_ / 3, sx = tap_ - r * 3;
-        const int tapoff = (r * hp.HWp + sx) * 64;
-        const unsigned char *sh = s_halo + (cb_ & 1) * halo_bytes;
-        const unsigned char *sw = s_w + (ph_ & 3) * WB;
-#pragma unroll
-        for (int j = 0; j < CT; j++) wf[j] = *reinterpret_cast<const half8_t *>(sw + (wn * 4 + j) * SUB + wfrag);
-#pragma unroll
-        for (int i = 0; i < PT; i++) {
-            const int L = hb0 + tapoff + ((((i * 16) >> hp.lgTW) * hp.HWp + ((i * 16) & (hp.TW - 1))) * 64);
-            xf[i] = *reinterpret_cast<const half8_t *>(sh + (L ^ ((L >> 3) & 32)));
-        }
-    };
-    auto multiply = [&](const half8_t (&wf)[CT], const half8_t (&xf)[PT]) {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < PT; i++)
-#pragma unroll
-            for (int j = 0; j < CT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-    };
-
-    // ---- prologue: halo of channel block 0, weights of phases 0..2, all landed; fragments of phase 0
-    for (int t = 0; t < 7; t++) stage_halo(t, 0, 0);
-    for (int q = 0; q < 3 && q < np; q++) stage_w(q);
-    wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    half8_t wfA[CT], xfA[PT], wfB[CT], xfB[PT];
-    read_frags(0, 0, 0, wfA, xfA);
-    int cb = 0, tap = 0;       // of phase ph
-    auto step = [&](int ph, half8_t (&wf_cur)[CT], half8_t (&xf_cur)[PT], half8_t (&wf_nxt)[CT], half8_t (&xf_nxt)[PT]) {
-        // DMA of this iteration: halo pieces of the next channel block, weights of phase ph + 3 (slot of phase ph - 1: free)
-        if (cb + 1 < ncb) stage_halo(tap, cb + 1, (cb + 1) & 1);
-        else {
-            lds_dma16(zp, s_dummy + wave * SUB);
-            lds_dma16(zp, s_dummy + wave * SUB);
-        }
-        if (ph + 3 < np) stage_w((ph + 3) & 3);
-        else {
-            lds_dma16(zp, s_dummy + wave * SUB);
-            lds_dma16(zp, s_dummy + wave * SUB);
-        }
-        int ncb_ = cb, ntap = tap + 1;
-        if (ntap == 9) {
-            ntap = 0;
-            ncb_ = cb + 1;
-        }
-        if (ph + 1 < np) read_frags(ph + 1, ncb_, ntap, wf_nxt, xf_nxt);   // next phase's fragments fly behind the MFMAs
-        multiply(wf_cur, xf_cur);
-        wait_vmcnt<NL>();   // everything issued before this iteration has landed (weights of phase ph + 2, older halo pieces)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        tap = ntap;
-        cb = ncb_;
-    };
-    int ph = 0;
-    for (; ph + 1 < np; ph += 2) {
-        step(ph, wfA, xfA, wfB, xfB);
-        step(ph + 1, wfB, xfB, wfA, xfA);
-    }
-    if (ph < np) step(ph, wfA, xfA, wfB, xfB);
-    wait_vmcnt<0>();
-
-    // ---- epilogue from registers (16-byte stores: epilogue_store)
-    epilogue_store<PT, CT>(acc, p, lane, n0 + wn * 64, [&](int i) -> long {
-        const int q = wm * 256 + i * 16 + (lane & 15);
-        const int qy = q >> hp.lgTW, qx = q & (hp.TW - 1);
-        return ((long)n_img * p.H + ty0 + qy) * p.W + tx0 + qx;
-    }, true);
-}
-
-// ------------------------------------------------------------------------------------------------ 3x3 halo, 16 waves
-// The same tile, halo buffers and weight ring once more, with FOUR waves per SIMD (1024 threads, 64 x 64 outputs and 64
-// accumulator registers per wave, < 128 VGPRs): no explicit stagger -- with four resident waves per SIMD the hardware overlaps
-// one wave's DMA issue / fragment reads / waits with the MFMAs of the other three, and the 16 MFMAs a wave issues per phase
-// only have to add up to the SIMD's 1024 cycles across its four waves.  Roles: waves 0..7 stream the weights (one sub-tile per
-// wave and phase, three phases ahead, counted vmcnt), waves 8..15 the next channel block's halo (one piece per wave in taps
-// 0..6, drained at tap 8).  One barrier per phase.
-template <bool ABLATE>
-__global__ __launch_bounds__(1024) void k_conv3x3_halo16(const ConvParams p, const HaloParams hp) {
-    constexpr int BN = 128, WB = BN * 32 * 2;
-    constexpr int PT = 4, CT = 4;   // 64 pixels x 64 channels per wave
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int halo_bytes = hp.npieces * SUB;
-    unsigned char *s_halo = smem;
-    unsigned char *s_w = smem + 2 * halo_bytes;
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const bool wloader = wave < 8;      // wave-uniform role
-    const int lw = wave & 7;            // index inside the role
-    const int n_img = blockIdx.x / hp.tiles, tile = blockIdx.x - n_img * hp.tiles;
-    const int ty0 = (tile / hp.tiles_x) * hp.TH, tx0 = (tile - (tile / hp.tiles_x) * hp.tiles_x) * hp.TW;
-    const int n0 = blockIdx.y * BN;
-    const char *xb = reinterpret_cast<const char *>(p.x) + (long)n_img * p.H * p.W * p.C * 2;
-    const char *wb = reinterpret_cast<const char *>(p.w);
-    const char *zp = reinterpret_cast<const char *>(p.zero);
-
-    // halo loaders: piece t * 8 + lw at tap t (t = 0..6); weight loaders: sub-tile lw of every phase
-    int hsrc[7];
-#pragma unroll
-    for (int t = 0; t < 7; t++) {
-        const int piece = t * 8 + lw;
-        const int phys = piece * SUB + lane * 16;
-        const int logical = phys ^ (((phys >> 8) & 1) << 5);
-        const int hpix = logical >> 6, chunk = (logical >> 4) & 3;
-        const int hy = hpix / hp.HWp, hx = hpix - hy * hp.HWp;
-        const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
-        const bool ok = piece < hp.npieces && hpix < hp.nhalo && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        hsrc[t] = ok ? ((iy * p.W + ix) * p.C * 2 + chunk * 16) : -1;
-    }
-    const int b = lane * 16;
-    const int bs = b ^ (((b >> 9) & 1) << 5);
-    const long woff = (long)(n0 + lw * 16 + (bs >> 6)) * (9L * p.C * 2) + (bs & 63);
-
-    const int ncb = p.C / 32;
-    const int np = ncb * 9;
-    int st_cb = 0, st_tap = 0;
-    auto stage_w = [&](int slot) {
-        lds_dma16(wb + woff + ((long)st_tap * p.C + (long)st_cb * 32) * 2, s_w + slot * WB + lw * SUB);
-        if (++st_tap == 9) {
-            st_tap = 0;
-            ++st_cb;
-        }
-    };
-    auto stage_halo = [&](int t, int cb, int buf) {   // only called with t < 7 and a piece inside the halo
-        int off = -1;
-#pragma unroll
-        for (int q = 0; q < 7; q++) off = t == q ? hsrc[q] : off;
-        const uintptr_t src = off >= 0 ? reinterpret_cast<uintptr_t>(xb) + (uintptr_t)((long)off + (long)cb * 64)
-                                       : reinterpret_cast<uintptr_t>(zp);
-        lds_dma16(reinterpret_cast<const void *>(src), s_halo + buf * halo_bytes + (t * 8 + lw) * SUB);
-    };
-
-    float4_t acc[PT][CT];
-#pragma unroll
-    for (int i = 0; i < PT; i++)
-#pragma unroll
-        for (int j = 0; j < CT; j++) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
-
-    const int wfrag = (lane & 15) * 64 + (((lane >> 4) * 16) ^ (((lane & 15) >> 3) << 5));
-    const int hb0 = (((wm * 64) >> hp.lgTW) * hp.HWp + ((wm * 64) & (hp.TW - 1)) + (lane & 15)) * 64 + (lane >> 4) * 16;
-
-    // ---- prologue: both roles load the first halo (7 pieces per wave pair), the weight loaders the slices of phases 0..2
-    for (int t = 0; t < 7; t++) {
-        const int piece = t * 16 + wave;   // 16 waves x 7 = 112 >= npieces
-        if (piece < hp.npieces) {
-            const int phys = piece * SUB + lane * 16;
-            const int logical = phys ^ (((phys >> 8) & 1) << 5);
-            const int hpix = logical >> 6, chunk = (logical >> 4) & 3;
-            const int hy = hpix / hp.HWp, hx = hpix - hy * hp.HWp;
-            const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
-            const bool ok = hpix < hp.nhalo && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const uintptr_t src = ok ? reinterpret_cast<uintptr_t>(xb) + (uintptr_t)((long)(iy * p.W + ix) * p.C * 2 + chunk * 16)
-                                     : reinterpret_cast<uintptr_t>(zp);
-            lds_dma16(reinterpret_cast<const void *>(src), s_halo + piece * SUB);
-        }
-    }
-    if (wloader)
-        for (int q = 0; q < 3 && q < np; q++) stage_w(q);
-    wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-
-    int cb = 0, tap = 0;
-    for (int ph = 0; ph < np; ph++) {
-        if (wloader) {
-            if (ph + 3 < np) stage_w((ph + 3) & 3);   // slot of phase ph - 1: every wave read it before the last barrier
-        } else if (cb + 1 < ncb && tap < 7 && tap * 8 + lw < hp.npieces) {
-            stage_halo(tap, cb + 1, (cb + 1) & 1);
-        }
-        const int r = tap / 3, sx = tap - r * 3;
-        const int tapoff = (r * hp.HWp + sx) * 64;
-        const unsigned char *sh = s_halo + (cb & 1) * halo_bytes;
-        const unsigned char *sw = s_w + (ph & 3) * WB;
-        half8_t wf[CT], xf[PT];
-#pragma unroll
-        for (int j = 0; j < CT; j++) wf[j] = *reinterpret_cast<const half8_t *>(sw + (wn * 4 + j) * SUB + wfrag);
-#pragma unroll
-        for (int i = 0; i < PT; i++) {
-            const int L = hb0 + tapoff + ((((i * 16) >> hp.lgTW) * hp.HWp + ((i * 16) & (hp.TW - 1))) * 64);
-            xf[i] = *reinterpret_cast<const half8_t *>(sh + (L ^ ((L >> 3) & 32)));
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < PT; i++)
-#pragma unroll
-            for (int j = 0; j < CT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        // retire what the NEXT phase reads: the weight slice of phase ph + 1 (weight loaders: the two newest may fly), and at
-        // the last tap of a channel block every halo piece of the next block (halo loaders)
-        if (wloader) {
-            if (ph + 3 < np) wait_vmcnt<2>();
-            else if (ph + 2 < np) wait_vmcnt<1>();
-            else wait_vmcnt<0>();
-        } else if (tap == 8) {
-            wait_vmcnt<0>();
-        }
-        __builtin_amdgcn_s_barrier();
-        if (++tap == 9) {
-            tap = 0;
-            ++cb;
-        }
-    }
-
-    // ---- epilogue from registers (16-byte stores: epilogue_store)
-    epilogue_store<PT, CT>(acc, p, lane, n0 + wn * 64, [&](int i) -> long {
-        const int q = wm * 64 + i * 16 + (lane & 15);
-        const int qy = q >> hp.lgTW, qx = q & (hp.TW - 1);
-        return ((long)n_img * p.H + ty0 + qy) * p.W + tx0 + qx;
-    }, true);
-}
-
+// geometry of the halo kernel for an image size, or false when the shape is not taken (the implicit-GEMM kernel runs it)
 void *g_zero_page = nullptr;
 
-// geometry of the halo kernel for an image size, or false when the shape is not taken (the implicit-GEMM kernel runs it)
 bool halo_geometry(const ConvParams &p, HaloParams &g) {
     if (p.R != 3 || p.pad != 1 || p.dil != 1 || p.C % 32 || p.K % 128) return false;
     if ((long)p.H * p.W * p.C * 2 >= (1L << 31)) return false;   // 32-bit byte offsets inside one image
@@ -994,37 +693,10 @@ bool halo_geometry(const ConvParams &p, HaloParams &g) {
     g.HWp = tw + 2;
     g.nhalo = (th + 2) * (tw + 2);
     g.npieces = (g.nhalo + 15) / 16;
-    return g.npieces <= 56;   // at most 7 or 8 pieces per wave and channel block, all three launch forms
+    return g.npieces <= 56;   // at most 7 pieces per wave and channel block
 }
 
-int launch_halo16(const ConvParams &p, const HaloParams &g, hipStream_t st) {
-    if (g.TW < 64) return PP_ERR_UNSUPPORTED;   // a wave's 64 pixels are whole 16-pixel runs of tile rows
-    const int lds = 2 * g.npieces * SUB + 4 * (128 * 32 * 2);
-    static int attr_lds = 0;
-    if (lds > attr_lds) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_halo16<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                lds) != hipSuccess)
-            return PP_ERR_HIP;
-        attr_lds = lds;
-    }
-    const dim3 grid((unsigned)(p.N * g.tiles), (unsigned)(p.K / 128));
-    hipLaunchKernelGGL((k_conv3x3_halo16<false>), grid, dim3(1024), lds, st, p, g);
-    return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
-}
 
-int launch_halo4(const ConvParams &p, const HaloParams &g, hipStream_t st) {
-    const int lds = 2 * g.npieces * SUB + 4 * (128 * 32 * 2) + 4 * SUB;
-    static int attr_lds = 0;
-    if (lds > attr_lds) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_halo4<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                lds) != hipSuccess)
-            return PP_ERR_HIP;
-        attr_lds = lds;
-    }
-    const dim3 grid((unsigned)(p.N * g.tiles), (unsigned)(p.K / 128));
-    hipLaunchKernelGGL((k_conv3x3_halo4<false>), grid, dim3(256), lds, st, p, g);
-    return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
-}
 
 template <int MASK, int LGTW>
 int launch_halo_inst(const ConvParams &p, const HaloParams &g, hipStream_t st) {
@@ -1143,7 +815,6 @@ PP_API int pp_conv_own_ex_f16(const void *x, const void *w, const void *bias, co
         ((reinterpret_cast<uintptr_t>(extra2) | reinterpret_cast<uintptr_t>(y2)) & 15))
         return PP_ERR_BAD_ARG;
     if ((upsampled_input || extra_mode == 3) && bn != 512) return PP_ERR_UNSUPPORTED;   // the 8-wave 3x3 halo kernel only
-    if (extra_mode == 4 && (bn == 514 || bn == 516)) return PP_ERR_UNSUPPORTED;
     if (upsampled_input && ((h | wd) & 1)) return PP_ERR_BAD_ARG;
     if (!pp_conv_own_supported(c_in, c_out, ksize)) return PP_ERR_UNSUPPORTED;
     if (!(slope >= 0.f && slope <= 1.f)) return PP_ERR_UNSUPPORTED;   // the epilogue's LeakyReLU is max(t, slope * t)
@@ -1152,7 +823,7 @@ PP_API int pp_conv_own_ex_f16(const void *x, const void *w, const void *bias, co
     if (al & 15) return PP_ERR_BAD_ARG;
     const int ho = h + 2 * pad - dilation * (ksize - 1), wo = wd + 2 * pad - dilation * (ksize - 1);
     if (ho <= 0 || wo <= 0) return PP_ERR_BAD_ARG;
-    if (bn != 0 && bn != 512 && bn != 514 && bn != 516 && ((bn != 256 && bn != 128 && bn != 64) || c_out % bn)) return PP_ERR_UNSUPPORTED;
+    if (bn != 0 && bn != 512 && ((bn != 256 && bn != 128 && bn != 64) || c_out % bn)) return PP_ERR_UNSUPPORTED;
     if (!g_zero_page) {
         if (hipMalloc(&g_zero_page, 256) != hipSuccess || hipMemset(g_zero_page, 0, 256) != hipSuccess) return PP_ERR_HIP;
     }
@@ -1175,9 +846,9 @@ PP_API int pp_conv_own_ex_f16(const void *x, const void *w, const void *bias, co
     static const int stagger = std::getenv("POSEPAF_CONV_STAGGER") ? std::atoi(std::getenv("POSEPAF_CONV_STAGGER")) : -1;   // -1: launcher's default
     p.stagger = stagger;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (bn == 0 || bn == 512 || bn == 514 || bn == 516) {   // 512 / 514 / 516: the halo-tile 3x3 kernels (8 / 4 / 16 waves)
+    if (bn == 0 || bn == 512) {   // 512: the halo-tile 3x3 kernel
         HaloParams g;
-        if (halo_geometry(p, g)) return bn == 514 ? launch_halo4(p, g, st) : (bn == 516 ? launch_halo16(p, g, st) : launch_halo(p, g, st));
+        if (halo_geometry(p, g)) return launch_halo(p, g, st);
         if (bn != 0) return PP_ERR_UNSUPPORTED;
         bn = c_out % 256 == 0 ? 256 : (c_out % 128 == 0 ? 128 : 64);
     }

@@ -27,10 +27,9 @@ USE_PWCONV = False
 # configurations AND the MIOpen-convolution + separate-epilogue path are timed once, at first (eager) use, and the fastest is kept.
 USE_FUSED_CONV = True
 # Hand-written implicit-GEMM / halo-tile convolution kernels (csrc/posepaf_conv_own.hip) compete in the same per-shape timing:
-# configuration ids >= 100 -> workgroup tile: 256 pixels x 256 / 128 / 64 channels, or 512 / 514 = the 3x3 halo-tile kernels
-# (8 / 4 / 16 waves)
+# configuration ids >= 100 -> workgroup tile: 256 pixels x 256 / 128 / 64 channels (implicit GEMM), or 512 = the 3x3 halo-tile kernel
 USE_OWN_CONV = True
-OWN_VARIANTS = {101: 256, 102: 128, 103: 64, 104: 512, 105: 514, 106: 516}
+OWN_VARIANTS = {101: 256, 102: 128, 103: 64, 104: 512}
 _conv_choice: dict = {}   # shape key -> tile configuration id, or -1 = MIOpen convolution + k_bias_act pass
 _conv_timing: dict = {}   # shape key -> {"miopen": ms, cfg: ms, ...} measured by the autotune (diagnostics)
 _conv_calls: dict = {}    # shape key -> number of forward() calls since import (diagnostics)

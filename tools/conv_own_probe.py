@@ -52,7 +52,7 @@ for (ci, co, h, w, k, pad, dil, mode) in SHAPES:
             continue
         res[f"ck{cfg}"] = timed(lambda: L.pp_conv_f16(*args))
     yck = y.clone()
-    for bn in (516, 514, 512, 256, 128, 64):
+    for bn in (512, 256, 128, 64):
         if bn < 512 and co % bn:
             continue
         args = (vp(x.data_ptr()), vp(wt.data_ptr()), vp(b.data_ptr()), vp(ex.data_ptr()) if mode else None, vp(y.data_ptr()), N, h, w,
