@@ -222,6 +222,9 @@ def test_evaluate_script_with_two_image_sizes(tmp_path):
     (1, 192, 384, 8, 8, 1, 0, 1),        # 1x1, BN = 128, three channel tiles
     (3, 64, 192, 9, 7, 3, 1, 1),         # ragged pixel count (189 rows: a partial 256-row tile), BN = 64 x 3
     (1, 320, 640, 5, 6, 3, 1, 1),        # more K-steps than pixels
+    (5, 64, 128, 120, 128, 1, 0, 1),     # 300 pixel tiles x 1 / 2 channel tiles on a persistent grid of 256 (512): several tiles per
+                                         # workgroup, the last ones on some workgroups only; two phases per tile (short K loop)
+    (3, 32, 64, 100, 128, 3, 2, 2),      # 150 ragged pixel tiles, dilated, nine phases per tile, one channel block
 ])
 def test_own_implicit_gemm_convolution_matches_torch(shape):
     """pp_conv_own_f16 (hand-written LDS-DMA + MFMA implicit GEMM, csrc/posepaf_conv_own.hip) against an fp32 torch convolution

@@ -1,3 +1,6 @@
+// What v_permlane16_swap_b32 does on gfx950 (used by the convolution epilogue, csrc/posepaf_conv_own.hip): prints, per lane, the two
+// returned values for x = 100 + lane, y = 200 + lane.  hipcc --offload-arch=gfx950 -O2 -o permlane16_swap_probe permlane16_swap_probe.hip
+// Observed: r0 = {even 16-lane rows: own x, odd rows: y of lane - 16}, r1 = {even rows: x of lane + 16, odd rows: own y}.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 __global__ void k(unsigned *a, unsigned *b) {
