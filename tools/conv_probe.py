@@ -7,6 +7,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "improved-body-parts_amd")):
     sys.path.insert(0, p)
+os.environ.setdefault("POSEPAF_TUNE_MIOPEN", "1")   # this table wants the MIOpen column too
 import torch
 from posepaf import fused_model as fm
 
@@ -30,7 +31,7 @@ for key, times in fm._conv_timing.items():
     t = times["miopen"] if best < 0 else times[best]
     flop = 2.0 * n * h * w * c * k * r * r
     byts = 2.0 * n * h * w * (c + k * (2 if mode else 1)) + 2.0 * k * c * r * r
-    rows.append((calls * t, key, calls, best, t, times["miopen"], flop / t / 1e9, byts / t / 1e6))
+    rows.append((calls * t, key, calls, best, t, times.get("miopen", float("nan")), flop / t / 1e9, byts / t / 1e6))
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
 print(f"{'c_in':>5} {'c_out':>5} {'hxw':>9} k pad dil mode act | calls cfg   best_ms  miopen_ms  TFLOP/s    GB/s  share")
