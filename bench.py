@@ -249,10 +249,10 @@ class GpuEngine:
         self.consumed = [torch.cuda.Event() for _ in range(2)]
         self.static_images = self.host[0].to(dev)
         self.k = 0
-        if rank == 0:   # the warm-up times every layer shape once (minutes): say so on stderr, one line per shape
+        if rank == 0:   # the warm-up times every layer shape once: say so on stderr, one line per shape
             from posepaf import fused_model as _fm
             _fm.set_progress(lambda msg: print(f"[bench] {msg}", file=sys.stderr, flush=True))
-            print(f"[bench] building the model; warm-up tunes each convolution shape at batch {a.batch} (a few minutes)", file=sys.stderr, flush=True)
+            print(f"[bench] building the model; warm-up tunes each convolution shape at batch {a.batch} (under a minute)", file=sys.stderr, flush=True)
         self.model = None if a.postproc_only else build_inference_model(dev, fused=not a.plain_model)
         self.pipe = PosePipeline(self.model, self.post, dtype=torch.float16, flip=True)
         self.scale = torch.tensor(1e-3, dtype=torch.float16, device=dev)
