@@ -58,6 +58,13 @@ __device__ __forceinline__ void lds_dma16(const void *gsrc, unsigned char *lds_w
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
+// The same through a buffer resource (buffer_load_dwordx4 ... offen lds): the address is base(rsrc) + voffset (per lane) + soffset
+// (scalar), so a load whose lane part is fixed costs NO address arithmetic, and a lane whose voffset lies outside num_records
+// gets ZEROS written to LDS (probed on gfx950: tools/buffer_lds_probe.hip) -- the zero padding of the convolution for free.
+__device__ __forceinline__ void lds_dma16_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset, unsigned soffset, unsigned char *lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)lds_wave_base, 16, (int)voffset, (int)soffset, 0, 0);
+}
+
 // Epilogue from registers with 16-byte stores.  After the MFMAs a lane holds, per (pixel tile i, channel tile j), four
 // consecutive channels (4 * (lane >> 4) ...) of pixel lane & 15: 8 bytes.  A row-per-lane epilogue of 8-byte stores is
 // store-ISSUE bound (32 of them per lane here).  Lanes l and l ^ 16 hold ADJACENT channel quads of the same pixel, so channel
@@ -379,7 +386,6 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     const int ptiles = p.N * hp.tiles, per_xcd = (ptiles + 7) >> 3;
     const int total_ids = 8 * per_xcd * nct;
     const char *wb = reinterpret_cast<const char *>(p.w);
-    const char *zp = reinterpret_cast<const char *>(p.zero);
     int n_img = 0, ty0 = 0, tx0 = 0, n0 = 0;   // the tile being STAGED (wave-uniform)
     const char *xb = nullptr;
     // ---- halo DMA sources.  A piece is 16 halo pixels x 64 B, lane-linear in LDS; the swizzle is applied on the source side.
@@ -389,7 +395,12 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     // swizzle (bit 9) would make 14 of 16 start offsets 2-way conflicted.
     // Wave w loads pieces w, w + 8, ..., w + 48 of every channel block (see the DMA schedule).
     int hsrc[7];   // byte offset inside the image for channel block 0, or -1: zero page (outside the image / past the halo)
-    long woff = 0; // weight sub-tile of this wave: 16 output channels x 32 halves per phase
+    unsigned woff = 0; // weight sub-tile of this wave: 16 output channels x 32 halves per phase (lane part of the offset)
+    int bx_lo = 0, bx_hi = 0, bw_lo = 0, bw_hi = 0, nx = 0;   // buffer bases (this image / this wave's 16 weight rows) and the image's bytes
+    auto rsrc_of = [&](int lo, int hi, int nbytes) {
+        void *base = reinterpret_cast<void *>(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+        return __builtin_amdgcn_make_buffer_rsrc(base, 0, nbytes, 0x00020000);
+    };
     auto decode = [&](int id) -> bool {   // id -> tile; false: padding of an XCD's range
         const int xcd = id & 7, q = id >> 3;
         const int ptile = xcd * per_xcd + q / nct, ctile = q - (q / nct) * nct;
@@ -412,11 +423,18 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
             const int hy = hpix / HWp, hx = hpix - hy * HWp;
             const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
             const bool ok = hpix < NHALO && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            hsrc[t] = ok ? (((iy >> p.up) * sw_ + (ix >> p.up)) * p.C * 2 + chunk * 16) : -1;
+            hsrc[t] = ok ? (((iy >> p.up) * sw_ + (ix >> p.up)) * p.C * 2 + chunk * 16) : (int)0x80000000;   // outside num_records: zeros
         }
         const int b = ln * 16;
         const int bs = b ^ (((b >> 9) & 1) << 5);
-        woff = (long)(n0 + wave * 16 + (bs >> 6)) * (9L * p.C * 2) + (bs & 63);
+        woff = (unsigned)((bs >> 6) * (9 * p.C * 2) + (bs & 63));   // lane part: row of the sub-tile, byte inside the 32-half k slice
+        // buffer resources (scalar): this image (bounds = the image: border pixels read zeros), this wave's 16 weight rows
+        // (kept as explicitly wave-uniform dwords: a resource the compiler cannot prove uniform costs a waterfall loop per load)
+        const unsigned long long ax = reinterpret_cast<unsigned long long>(xb);
+        const unsigned long long aw = reinterpret_cast<unsigned long long>(wb) + (unsigned long long)((long)(n0 + wave * 16) * (9L * p.C * 2));
+        bx_lo = __builtin_amdgcn_readfirstlane((int)(unsigned)ax), bx_hi = __builtin_amdgcn_readfirstlane((int)(unsigned)(ax >> 32));
+        bw_lo = __builtin_amdgcn_readfirstlane((int)(unsigned)aw), bw_hi = __builtin_amdgcn_readfirstlane((int)(unsigned)(aw >> 32));
+        nx = __builtin_amdgcn_readfirstlane((p.up ? p.H >> 1 : p.H) * sw_ * p.C * 2);
         return true;
     };
     auto next_tile = [&](int id) -> int {   // first valid id at or after `id` on this workgroup's stride, or total_ids
@@ -430,7 +448,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     int st_slot = 0;
     int slot_cur = 0;            // ring slot of the phase being multiplied
     auto stage_w = [&]() {
-        lds_dma16(wb + woff + ((long)st_tap * p.C + (long)st_cb * 32) * 2, s_w + st_slot * WB + wave * SUB);
+        lds_dma16_buf(rsrc_of(bw_lo, bw_hi, 16 * 9 * p.C * 2), woff, (unsigned)((st_tap * p.C + st_cb * 32) * 2), s_w + st_slot * WB + wave * SUB);
         if (++st_slot == NW) st_slot = 0;
         if (++st_tap == 9) {
             st_tap = 0;
@@ -438,12 +456,8 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
         }
     };
     auto stage_halo = [&](int t, int cb, int buf) {   // piece t * 8 + wave (t compile-time 0..6) of channel block cb
-        // 32-bit offsets inside the image (< 2^31 bytes: checked by the launcher)
-        int h = hsrc[t];
-        asm volatile("" : "+v"(h));   // opaque: otherwise seven running 64-bit pointers (and their zero-page selects) live in registers
-        const uintptr_t src = h >= 0 ? reinterpret_cast<uintptr_t>(xb) + (uintptr_t)(unsigned)(h + cb * 64)
-                                     : reinterpret_cast<uintptr_t>(zp);
-        lds_dma16(reinterpret_cast<const void *>(src), s_halo + buf * halo_bytes + (t * 8 + wave) * SUB);
+        // 32-bit offsets inside the image (< 2^31 bytes: checked by the launcher); the channel block is the scalar offset
+        lds_dma16_buf(rsrc_of(bx_lo, bx_hi, nx), (unsigned)hsrc[t], (unsigned)(cb * 64), s_halo + buf * halo_bytes + (t * 8 + wave) * SUB);
     };
 
     // fragment addresses.  Weights: sub-tile image as above.  Pixels: lane reads 16 B (k group g) of halo pixel
