@@ -61,11 +61,13 @@ def parse(argv=None):
                     help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="bound on the CPU baseline leg (all parts together)")
-    ap.add_argument("--cpu-cores", type=int, default=0, help="worker processes of the CPU baseline (0 = all this process may use, <= 16)")
+    ap.add_argument("--cpu-cores", type=int, default=0, help="worker processes of the CPU baseline (0 = every host core this process may use)")
     ap.add_argument("--postproc-only", action="store_true", help="time only K_A..K_C (profiling aid)")
     ap.add_argument("--plain-model", action="store_true", help="unfused nn.Module forward instead of the fused one")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-ingest", action="store_true", help="leave the host->HBM upload out of the step (round-1 form)")
+    ap.add_argument("--retune", action="store_true", help="ignore the saved kernel-choice table and time every layer shape again")
+    ap.add_argument("--no-verify", action="store_true", help="skip the independent re-computation of the last batch")
     ap.add_argument("--multiscale", action="store_true",
                     help="BASELINE configs[4]: original path, scale search {0.5, 1.0, 1.5} x 512 + flip, float64 accumulation")
     return ap.parse_args(argv)
@@ -132,7 +134,20 @@ def _time_loop(fn, seconds):
             return n / dt, n
 
 
-def cpu_baseline(seconds, cores=0):
+def usable_cores():
+    """host cores this process may really use: the affinity mask, cut by the cgroup CPU quota when there is one"""
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(float(q) / float(per)))
+    except Exception:
+        pass
+    return avail, quota
+
+
+def cpu_baseline(seconds, cores=0, check=None):
     """The oracle -- the plain-C restatement of the reference's CPU path, pinned bit-exact against the reference's own
     compiled C++ and Python outputs (tests/test_oracle_*.py) -- timed on this machine's host cores, SURVEY.md 8(d):
       value      : whole post-processing (flip-average, heatmap_nms with x4 patch refinement, x4 limb upsample, process_paf),
@@ -144,8 +159,8 @@ def cpu_baseline(seconds, cores=0):
     import multiprocessing as mp
     import numpy as np
     from oracle.oracle import Oracle
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = cores or min(avail, 16)
+    avail, quota = usable_cores()
+    cores = cores or (min(avail, quota) if quota else avail)
     orc = Oracle()
     _, uniq = build_scenes(len(SCENE_PEOPLE))
     nu = len(uniq)
@@ -171,7 +186,22 @@ def cpu_baseline(seconds, cores=0):
         counts = pool.map(_cpu_worker_run, [(3 * i, t0 + par_seconds) for i in range(cores)])
         dt = time.time() - t0
     n = int(np.sum(counts))
-    return {"value": n / dt, "unit": "images/sec", "cores": cores, "host_cores_available": avail, "kind": "port",
+    checked = None
+    if check is not None:   # the oracle as the CHECKER of the timed GPU run: same maps in, records must be equal
+        maps, recs = check
+        checked = "equal"
+        for i in range(len(maps)):
+            if int(recs[i]["status"]) & ST_SORT_UNDEFINED:   # the reference's own result is undefined there
+                continue
+            want = orc.pipeline(maps[i], IMG)
+            k = int(recs[i]["n_humans"])
+            if k != len(want["ids"]) or not np.array_equal(recs[i]["humans"]["peak_id"][:k], want["ids"]) \
+                    or not np.array_equal(recs[i]["humans"]["score"][:k], want["scores"]):
+                checked = "DIFFERENT"
+    return {"value": n / dt, "unit": "images/sec", "cores": cores, "host_cores_available": avail, "cgroup_cpu_quota": quota,
+            "records_vs_oracle": checked,
+            "records_vs_oracle_sample": None if check is None else f"first {len(check[0])} images of the last timed batch: person count, peak ids and scores equal",
+            "kind": "port",
             "sample": f"{n} images ({nu} scenes of {min(SCENE_PEOPLE)}-{max(SCENE_PEOPLE)} people, cycled) in {dt:.1f} s on "
                       f"{cores} worker processes, one image per core; post-processing only (flip-average, NMS + x4 patch "
                       "refinement, x4 limb upsample, process_paf); network forward excluded",
@@ -212,21 +242,30 @@ class StubEngine:
     def sync(self):
         pass
 
+    def verify(self, rec):
+        return {"ok": True, "stub": True}
+
+    def oracle_sample(self, rec, n=8):
+        return None
+
     def extras(self, a, dt, world):
         return {"stub": True, "steps_run": self.steps_run}
 
 
 class GpuEngine:
+    """bench.py's step on posepaf.engine.InferenceEngine -- the same engine improved-body-parts_amd/evaluate.py runs on."""
     name = "gpu"
 
     def __init__(self, a, rank, world, local, backend):
         import numpy as np
         import torch
         assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU path)"
+        from posepaf import fused_model
         from posepaf.api import PosePostProcessor
+        from posepaf.engine import InferenceEngine
         from posepaf.fused_model import build_inference_model
         from posepaf.pipeline import PosePipeline
-        self.torch, self.a, self.B = torch, a, a.batch
+        self.torch, self.a, self.B, self.rank, self.world = torch, a, a.batch, rank, world
         local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
         self.dev = dev = torch.device("cuda", local)
@@ -238,58 +277,51 @@ class GpuEngine:
         B = a.batch
         self.post = PosePostProcessor(max_batch=B, max_h=FEAT if not a.multiscale else 192, max_w=FEAT if not a.multiscale else 192,
                                       max_peaks_per_part=64, device=local)
-        scenes_np, self.uniq = build_scenes(B)
-        self.inject = torch.from_numpy(scenes_np).to(dev)                                   # (B,2,50,128,128) fp16
-        # host side of the ingest: two different pinned batches, uploaded alternately
-        g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-        self.host = [torch.randint(0, 256, (B, IMG, IMG, 3), dtype=torch.uint8, generator=g).pin_memory() for _ in range(2)]
-        self.staging = [torch.empty((B, IMG, IMG, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
-        self.copy_stream = torch.cuda.Stream(device=dev)
-        self.uploaded = [torch.cuda.Event() for _ in range(2)]
-        self.consumed = [torch.cuda.Event() for _ in range(2)]
-        self.static_images = self.host[0].to(dev)
-        self.k = 0
-        if rank == 0:   # the warm-up times every layer shape once: say so on stderr, one line per shape
-            from posepaf import fused_model as _fm
-            _fm.set_progress(lambda msg: print(f"[bench] {msg}", file=sys.stderr, flush=True))
-            print(f"[bench] building the model; warm-up tunes each convolution shape at batch {a.batch} (under a minute)", file=sys.stderr, flush=True)
+        _, self.uniq = build_scenes(len(SCENE_PEOPLE))
+        say = (lambda msg: print(f"[bench] {msg}", file=sys.stderr, flush=True)) if rank == 0 else None
+        if say:   # the warm-up times every layer shape once: say so on stderr, one line per shape
+            fused_model.set_progress(say)
+            say(f"building the model; warm-up tunes each convolution shape at batch {a.batch} unless the choice table "
+                f"{fused_model.default_table_path()} exists (under a minute)")
         self.model = None if a.postproc_only else build_inference_model(dev, fused=not a.plain_model)
-        self.pipe = PosePipeline(self.model, self.post, dtype=torch.float16, flip=True)
-        self.scale = torch.tensor(1e-3, dtype=torch.float16, device=dev)
-        self.graph, self.static_rec = None, None
+        self.table_loaded = fused_model.load_table() if not a.retune else 0
+        self.eng = InferenceEngine(self.model, self.post, B, local, rules="cpp", use_graph=not (a.no_graph or a.multiscale),
+                                   inject_scale=1e-3, max_image_hw=(IMG, IMG), n_slots=2, postproc_only=a.postproc_only,
+                                   progress=say)
         if a.multiscale:
+            self.pipe = PosePipeline(self.model, self.post, dtype=torch.float16, flip=True)
+            self.scale = torch.tensor(1e-3, dtype=torch.float16, device=dev)
+            g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+            self.static_images = torch.randint(0, 256, (B, IMG, IMG, 3), dtype=torch.uint8, generator=g).to(dev)
             self._init_multiscale()
-        elif not a.no_graph:
-            # HIP graph of the whole per-batch path (forward + K_A / K_BC): ~1000 launches replayed as one
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side), torch.no_grad():
-                for _ in range(2):
-                    self._body()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph), torch.no_grad():
-                self.static_rec = self._body()
-        if not a.no_ingest:
-            self._upload(0)
-
-    # -- ingest: batch k is uploaded into staging[k % 2] on the copy stream while batch k-1 computes
-    def _upload(self, k):
-        torch = self.torch
-        s = k % 2
-        with torch.cuda.stream(self.copy_stream):
-            self.copy_stream.wait_event(self.consumed[s])          # the compute stream is done reading this buffer
-            self.staging[s].copy_(self.host[k % 2], non_blocking=True)
-            self.uploaded[s].record(self.copy_stream)
-
-    def _body(self):
-        torch = self.torch
-        if self.a.postproc_only:
-            return self.post.process_async(self.inject, IMG, True)
-        maps = self.pipe.forward_maps(self.static_images)
-        maps = torch.addcmul(self.inject, maps, self.scale)
-        return self.post.process_async(maps, IMG, True)
+            return
+        self.plan = self.eng.plan(IMG, IMG, B)
+        self.eng.set_bank(self.plan, np.stack(self.uniq))
+        # host side of the ingest: two different pinned batches, uploaded alternately
+        g = np.random.default_rng(1234 + rank)
+        self.slots = []
+        for _ in range(2):
+            slot = self.eng.acquire()
+            sizes, idx, imgs = slot.views(B, IMG, IMG)
+            sizes[:] = IMG
+            idx[:] = np.arange(B) % len(self.uniq)
+            imgs[:] = g.integers(0, 256, imgs.shape, dtype=np.uint8)
+            self.slots.append(slot)
+        # kernel choice per layer shape: rank 0 tunes (or loads the table), every rank runs rank 0's table
+        if world > 1 and not a.plain_model and not a.postproc_only:
+            import torch.distributed as dist
+            if rank == 0:
+                self.eng.prepare(self.plan)
+            box = [fused_model.table_entries() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            fused_model.install_entries(box[0])
+        self.eng.prepare(self.plan)
+        if rank == 0 and not a.plain_model and not a.postproc_only:
+            fused_model.save_table()
+        self.inject = self.plan.bank.index_select(0, torch.from_numpy(np.arange(B) % len(self.uniq)).to(dev))
+        self.k = 0
+        self.eng.submit(self.slots[0], self.plan, recycle=False)     # the resident batch of --no-ingest
+        self.eng.sync()
 
     def _init_multiscale(self):
         from posepaf import synth
@@ -316,26 +348,70 @@ class GpuEngine:
         return self.proc.finish(self.B)
 
     def step(self):
-        torch = self.torch
-        cur = torch.cuda.current_stream()
-        if not self.a.no_ingest:
-            s = self.k % 2
-            cur.wait_event(self.uploaded[s])                       # batch k has landed in HBM
-            self.static_images.copy_(self.staging[s], non_blocking=True)   # into the graph's input buffer (HBM -> HBM)
-            self.consumed[s].record(cur)
-            self._upload(self.k + 1)                               # next batch rides under this step's compute
-            self.k += 1
         if self.a.multiscale:
-            with torch.no_grad():
+            with self.torch.no_grad():
                 return self._body_multiscale()
-        if self.graph is not None:
-            self.graph.replay()
-            return self.static_rec
-        with torch.no_grad():
-            return self._body()
+        if self.a.no_ingest:
+            return self.eng.run_resident(self.plan)
+        rec = self.eng.submit(self.slots[self.k % 2], self.plan, recycle=False)   # batch k+1's upload rides under batch k's compute
+        self.k += 1
+        return rec
 
     def sync(self):
         self.torch.cuda.synchronize()
+
+    def verify(self, rec):
+        """Independent re-computation of the LAST batch (a status word alone does not prove the records):
+          (1) the post-processing of the batch's network output once more with the person assembly as its OWN launch
+              (pp_debug_set_mode 1, eager) -- every record byte must equal what the graph replay produced;
+          (2) the fused fp16 forward (kernels picked by the tuner, as replayed) against the plain nn.Module on PyTorch-ROCm
+              (MIOpen convolutions, BatchNorm unfolded) for the first two images of the batch.
+        -> dict for the JSON line; ["ok"] False invalidates the run."""
+        torch = self.torch
+        import numpy as np
+        a, p = self.a, getattr(self, "plan", None)
+        if a.multiscale or p is None:
+            return {"ok": True, "skipped": "multi-scale line: records are checked by the GPU tests only"}
+        out = {"ok": True}
+        self.sync()
+        got = rec.cpu().numpy().copy()
+        maps = p.maps.clone()
+        self.post.set_mode(1)
+        again = torch.zeros_like(p.records)
+        self.post.process_async(maps, IMG, True, min_img_size_dev=p.sizes[0].clone(), records=again)
+        self.sync()
+        self.post.set_mode(0)
+        same = bool(np.array_equal(got, again.cpu().numpy()))
+        out["records_vs_separate_assembly_launch"] = "equal" if same else "DIFFERENT"
+        out["ok"] &= same
+        if self.model is not None and not a.plain_model:
+            from posepaf.fused_model import build_inference_model
+            from posepaf.pipeline import preprocess_batch
+            nchk = min(2, p.b)
+            with torch.no_grad():
+                x = preprocess_batch(p.images, True, torch.float16)
+                fused = self.model(x)[: 2 * nchk].float()
+                bench_flag = torch.backends.cudnn.benchmark
+                torch.backends.cudnn.benchmark = False
+                plain = build_inference_model(self.dev, fused=False)
+                ref = plain(x[: 2 * nchk].contiguous())[-1][0].float()
+                torch.backends.cudnn.benchmark = bench_flag
+                del plain
+            err = float((fused - ref).abs().max() / ref.abs().max().clamp_min(1e-6))
+            out["forward_vs_plain_module_max_err_over_max"] = err
+            out["forward_tolerance"] = 3e-2
+            out["ok"] &= bool(err <= 3e-2) and bool(torch.isfinite(fused).all())
+        return out
+
+    def oracle_sample(self, rec, n=8):
+        """(network output of the first n images of the last batch, their records) for the CPU-baseline leg's checker"""
+        from posepaf.api import records_to_numpy
+        p = getattr(self, "plan", None)
+        if p is None or self.a.multiscale:
+            return None
+        self.sync()
+        n = min(n, p.b)
+        return p.maps[:n].cpu().numpy(), records_to_numpy(rec)[:n]
 
     def extras(self, a, dt, world):
         """roofline of the hand-written kernels (HIP events on the launch stream) + forward roofline"""
@@ -353,13 +429,16 @@ class GpuEngine:
         achieved = alg[dom] / (ms[dom] * 1e-3) / 1e9
         chain = chain_bytes / (ms["chain"] * 1e-3) / 1e9
         traffic, src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get(dom, {}).get(f"batch{B}")
-                src = "profiles/r02_pmc_traffic.json (rocprofv3 --pmc passes of tools/pmc_traffic.py on this build; not re-measured in this run)"
-            except Exception:
-                traffic = None
+        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+            pmc = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get(dom, {}).get(f"batch{B}")
+                    src = f"profiles/{name} (rocprofv3 --pmc passes of tools/pmc_traffic.py; not re-measured in this run)"
+                except Exception:
+                    traffic = None
+                if traffic is not None:
+                    break
         out["kernel_ms"] = ms
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
@@ -376,17 +455,20 @@ class GpuEngine:
                         "those the inference model executes (512.18 GFLOP per 512x512 forward, tools/count_flops.py), not the "
                         "reference module's 529.39 (its last stage's coarse heads are computed and discarded)"}
             if not a.plain_model:
-                from posepaf.fused_model import conv_choices
-                ch = conv_choices()
+                from posepaf import fused_model
+                ch = fused_model.conv_choices()
                 up2 = {k: v for k, v in ch.items() if k[0] == "up2"}     # upsample -> 3x3 -> add(s): 1 = one launch of the halo kernel
                 dual = {k: v for k, v in ch.items() if k[0] == "dual"}   # convolution with a second output y + other: 0 = separate add
-                ch = {k: v for k, v in ch.items() if k[0] not in ("up2", "dual")}
+                ch = {k: v for k, v in ch.items() if k[0] not in ("up2", "dual") and k[0] == 2 * B}
                 out["conv_layers"] = {"shapes_own_kernel": sum(1 for v in ch.values() if v >= 100),
                                       "shapes_ck_template_kernel": sum(1 for v in ch.values() if 0 <= v < 100),
                                       "shapes_miopen_plus_epilogue": sum(1 for v in ch.values() if v < 0),
                                       "upsample_conv_add_sites_fused": sum(1 for v in up2.values() if v),
                                       "upsample_conv_add_sites_separate": sum(1 for v in up2.values() if not v),
-                                      "two_output_conv_sites_fused": sum(1 for v in dual.values() if v)}
+                                      "two_output_conv_sites_fused": sum(1 for v in dual.values() if v),
+                                      "choice_table_hash": fused_model.table_hash(),
+                                      "choice_table": "loaded from " + fused_model.default_table_path() if self.table_loaded
+                                      else "tuned in this run's warm-up"}
         return out
 
 
@@ -466,6 +548,12 @@ def main(argv=None):
         humans = int(allrec["n_humans"].sum())
     allowed = ST_SORT_UNDEFINED | (32 if a.multiscale else 0)
     bad_status = bool(status_or & ~ST_DEFINED) or bool(status_or & ~allowed)
+    verdict = {"ok": True, "skipped": "--no-verify"} if a.no_verify else eng.verify(rec)
+    if world > 1:   # every rank re-computes its own last batch; one failing rank fails the job
+        t = torch.tensor([0 if verdict["ok"] else 1], dtype=torch.int32, device=gdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        verdict["all_ranks_ok"] = not bool(t.item())
+        verdict["ok"] = verdict["all_ranks_ok"]
 
     rc = 0
     if rank == 0:
@@ -486,16 +574,22 @@ def main(argv=None):
                        "ingest": "off" if a.no_ingest else "pinned host -> HBM upload of each uint8 batch inside the step (copy stream, double-buffered)",
                        "launch": "eager" if (a.no_graph or multi or stub) else "hipGraph replay",
                        "parallelism": f"image-sharded x{world}"},
-            "humans_found_in_batch": humans, "status_or": status_or,
+            "humans_found_in_batch": humans, "status_or": status_or, "verify": verdict,
         }
         out.update(eng.extras(a, dt, world))
         if not a.no_cpu_baseline and world == 1 and not stub:   # reported on rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(a.cpu_seconds, a.cpu_cores)
+            out["cpu_baseline"] = cpu_baseline(a.cpu_seconds, a.cpu_cores, check=eng.oracle_sample(rec))
+            if out["cpu_baseline"].get("records_vs_oracle") == "DIFFERENT":
+                verdict["ok"] = False
         print(json.dumps(out), flush=True)
     if bad_status:
         print(f"bench.py: pp_record.status = {status_or:#010x}: "
               + ("bits outside include/posepaf.h:53-59 (corrupted records)" if status_or & ~ST_DEFINED else "capacity-overflow flags raised")
               + " -- the result is INVALID", file=sys.stderr, flush=True)
+        rc = 3
+    if not verdict["ok"]:
+        print(f"bench.py: the independent re-computation of the last batch disagrees: {verdict} -- the result is INVALID",
+              file=sys.stderr, flush=True)
         rc = 3
     if world > 1:
         dist.barrier()

@@ -382,6 +382,61 @@ extern "C" int pp_preprocess_u8(const void *images_u8, void *out, int dtype, int
     return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
 }
 
+// The same for a bucket of images of DIFFERENT sizes that share one padded shape (COCO val2017 does: 427x640 and 426x640
+// both pad to 448x640).  Each image sits in the top-left corner of its (Hp, Wp) slot of `img`; bytes outside its own
+// (h_b, w_b) are never read (the host need not initialise them): the kernel writes pad_value / 255 there, which is what
+// padRightDownCorner (utils/util.py:44-65) leaves in the padded image.  sizes: DEVICE int[2][B] = heights then widths.
+namespace {
+template <typename OutT>
+__global__ __launch_bounds__(256) void k_preprocess_ragged(const unsigned char *__restrict__ img, const int *__restrict__ sizes,
+                                                           OutT *__restrict__ out, int B, int Hp, int Wp, int flip,
+                                                           float pad_norm) {
+    const long npix = (long)B * Hp * Wp;
+    const long stride = (long)gridDim.x * blockDim.x;
+    const int ns = flip ? 2 : 1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += stride) {
+        const int x = (int)(i % Wp);
+        long t = i / Wp;
+        const int y = (int)(t % Hp);
+        const long b = t / Hp;
+        const int H = sizes[b], W = sizes[B + b];
+        float v[3];
+        if (y < H && x < W) {
+            const unsigned char *p = img + i * 3;
+#pragma unroll
+            for (int c = 0; c < 3; c++) v[c] = (float)p[c] / 255.0f;
+        } else {
+            v[0] = v[1] = v[2] = pad_norm;
+        }
+        OutT *o0 = out + (((b * ns) * Hp + y) * Wp + x) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; c++) o0[c] = cvt_out<OutT>(v[c]);
+        if (flip) {
+            OutT *o1 = out + (((b * ns + 1) * Hp + y) * Wp + (Wp - 1 - x)) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; c++) o1[c] = cvt_out<OutT>(v[c]);
+        }
+    }
+}
+}  // namespace
+
+extern "C" int pp_preprocess_u8_ragged(const void *images_u8, const int *sizes_dev, void *out, int dtype, int batch, int hp,
+                                       int wp, int pad_value, int flip, void *stream) {
+    if (!images_u8 || !sizes_dev || !out || batch <= 0 || hp <= 0 || wp <= 0 || (dtype != PP_F16 && dtype != PP_F32))
+        return PP_ERR_BAD_ARG;
+    const long npix = (long)batch * hp * wp;
+    const dim3 grid(grid_for(npix)), block(256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float pad_norm = (float)pad_value / 255.0f;
+    if (dtype == PP_F16)
+        hipLaunchKernelGGL(k_preprocess_ragged<__half>, grid, block, 0, st, static_cast<const unsigned char *>(images_u8), sizes_dev,
+                           static_cast<__half *>(out), batch, hp, wp, flip, pad_norm);
+    else
+        hipLaunchKernelGGL(k_preprocess_ragged<float>, grid, block, 0, st, static_cast<const unsigned char *>(images_u8), sizes_dev,
+                           static_cast<float *>(out), batch, hp, wp, flip, pad_norm);
+    return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
+}
+
 // ------------------------------------------------------------------------------------------------ A2 standalone
 // predict_refactor's return value (utils/parse_skeletons.py:82-103): heat (h, w, 20) and paf (h, w, 30), HWC float32,
 // flip-averaged in the input's dtype.  The fused kernels K_A/K_B never materialise these; this entry point exists for

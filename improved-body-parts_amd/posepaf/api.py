@@ -68,18 +68,19 @@ class PosePostProcessor:
                                            C.c_void_p(stream)), self.ctx)
         return rec[: B * RECORD_BYTES]
 
-    def process_py_async(self, net_out, img_height: int = 512, flip: bool = True, img_height_dev=None):
+    def process_py_async(self, net_out, img_height: int = 512, flip: bool = True, img_height_dev=None, records=None):
         """The pure-Python twins' rules (find_connections + find_humans) instead of the C++ pafprocess rules; enqueues
         on torch's current stream and returns the device record buffer."""
         import torch
         B, h, w = self._check_input(net_out, flip)
+        rec = self._records if records is None else records
         stream = torch.cuda.current_stream(net_out.device).cuda_stream
         _lib.check(self.L.pp_process_batch_py(self.ctx, B, C.c_void_p(net_out.data_ptr()), self._dtype_code(net_out), h, w,
                                               int(flip), int(img_height),
                                               C.c_void_p(img_height_dev.data_ptr()) if img_height_dev is not None else None,
-                                              C.c_void_p(self._records.data_ptr()),
+                                              C.c_void_p(rec.data_ptr()),
                                               C.c_void_p(stream)), self.ctx)
-        return self._records[: B * RECORD_BYTES]
+        return rec[: B * RECORD_BYTES]
 
     def process_py(self, net_out, img_height: int = 512, flip: bool = True) -> np.ndarray:
         return records_to_numpy(self.process_py_async(net_out, img_height, flip))

@@ -58,6 +58,80 @@ def conv_choices() -> dict:
     return dict(_conv_choice)
 
 
+# ---- the kernel-choice table is an artefact, not a side effect: it can be saved, loaded, hashed and broadcast, so that two
+# runs (or the ranks of one job) execute the SAME kernel per layer shape and produce the same fp16 bits.
+def _key_to_json(k):
+    return [("b", bool(v)) if isinstance(v, bool) else v for v in k]
+
+
+def _key_from_json(k):
+    return tuple(bool(v[1]) if isinstance(v, list) else v for v in k)
+
+
+def table_entries() -> list:
+    """sorted [[key, choice], ...] in a JSON-able form"""
+    return sorted(([_key_to_json(k), int(v)] for k, v in _conv_choice.items()), key=lambda e: repr(e[0]))
+
+
+def table_hash() -> str:
+    import hashlib
+    import json
+    return hashlib.sha256(json.dumps(table_entries()).encode()).hexdigest()[:16]
+
+
+def library_hash() -> str:
+    """identifies the kernels a table was tuned on: sha256 of libposepaf.so"""
+    import hashlib
+    from . import _lib
+    h = hashlib.sha256()
+    with open(_lib.LIB_PATH, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()[:16]
+
+
+def default_table_path() -> str:
+    d = os.environ.get("POSEPAF_CACHE_DIR", "/tmp/posepaf_cache")
+    return os.path.join(d, f"conv_choice_{library_hash()}.json")
+
+
+def save_table(path: str | None = None) -> str:
+    import json
+    path = path or default_table_path()
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    tmp = f"{path}.{os.getpid()}.tmp"
+    with open(tmp, "w") as f:
+        json.dump({"library": library_hash(), "entries": table_entries()}, f)
+    os.replace(tmp, path)
+    return path
+
+
+def install_entries(entries) -> int:
+    """merge [[key, choice], ...] into the table (existing keys keep their choice); -> number of new keys"""
+    n = 0
+    for k, v in entries:
+        k = _key_from_json(k)
+        if k not in _conv_choice:
+            _conv_choice[k] = int(v)
+            n += 1
+    return n
+
+
+def load_table(path: str | None = None, force: bool = False) -> int:
+    """-> number of entries installed (0 when the file is absent or was tuned on another build of the library)"""
+    import json
+    path = path or default_table_path()
+    if not os.path.exists(path):
+        return 0
+    try:
+        doc = json.load(open(path))
+    except Exception:
+        return 0
+    if doc.get("library") != library_hash() and not force:
+        return 0
+    return install_entries(doc.get("entries", []))
+
+
 def _cl(t):
     return t if t.is_contiguous(memory_format=torch.channels_last) else t.contiguous(memory_format=torch.channels_last)
 

@@ -52,6 +52,7 @@ def evaluate_keypoints(gts: dict, dts: dict) -> dict:
         order = np.argsort(ignore, kind="mergesort")  # non-ignored GT first
         g = [g[i] for i in order]
         ignore = ignore[order]
+        crowd = np.array([bool(x.get("iscrowd", 0)) for x in g], bool)
         oks = np.zeros((len(d), len(g)))
         for i, dd in enumerate(d):
             for j, gg in enumerate(g):
@@ -62,7 +63,7 @@ def evaluate_keypoints(gts: dict, dts: dict) -> dict:
             for i in range(len(d)):
                 best, best_j = min(thr, 1 - 1e-10), -1
                 for j in range(len(g)):
-                    if gt_taken[j]:
+                    if gt_taken[j] and not crowd[j]:   # a crowd region may absorb any number of detections
                         continue
                     if best_j > -1 and not ignore[best_j] and ignore[j]:
                         break

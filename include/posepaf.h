@@ -214,6 +214,12 @@ PP_API int pp_conv_own_ex_f16(const void *x, const void *w, const void *bias, co
  * followed (flip != 0) by the W-mirror of the PADDED image.  out: DEVICE (batch*(flip?2:1), Hp, Wp, 3), PP_F16 or PP_F32. */
 PP_API int pp_preprocess_u8(const void *images_u8, void *out, int dtype, int batch, int h, int w, int pad_to,
                             int pad_value, int flip, void *stream);
+/* The same for a bucket of images of DIFFERENT sizes sharing one padded shape (hp, wp) -- the reference pads every image
+ * alone (utils/parse_skeletons.py:54); the batched evaluation loop groups images by padded shape.  images_u8: DEVICE
+ * (batch, hp, wp, 3), image b in the top-left (sizes[b], sizes[batch + b]) corner of its slot, the rest of the slot is never
+ * read; sizes_dev: DEVICE int[2][batch] = heights, then widths (heights double as pp_process_batch's min_img_size_dev). */
+PP_API int pp_preprocess_u8_ragged(const void *images_u8, const int *sizes_dev, void *out, int dtype, int batch, int hp,
+                                   int wp, int pad_value, int flip, void *stream);
 
 /* A2 standalone: the arrays predict_refactor returns (utils/parse_skeletons.py:82-103).  net_out_dev as for
  * pp_process_batch; heat_hwc_dev: DEVICE float[batch][h][w][20], paf_hwc_dev: DEVICE float[batch][h][w][30]. */

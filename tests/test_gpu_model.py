@@ -468,14 +468,90 @@ def test_evaluate_two_ranks_on_one_gpu_gloo_rehearsal(tmp_path):
         summary = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
         assert summary["world"] == gpus and summary["images"] == 5 and summary["status_or"] == 0
         outs.append(json.load(open(dump)))
-    # the forward of an image depends (in its last fp16 bits) on the batch it runs in, so people are compared with a tolerance:
-    # same images, same number of people per image in the same order, joints within one feature-map cell, scores within 1e-2
-    assert len(outs[0]) >= 10 and len(outs[0]) == len(outs[1])
-    for a_, b_ in zip(outs[0], outs[1]):
-        assert a_["image_id"] == b_["image_id"]
-        ka, kb = np.array(a_["keypoints"]).reshape(17, 3), np.array(b_["keypoints"]).reshape(17, 3)
-        assert np.array_equal(ka[:, 2], kb[:, 2]) and np.abs(ka[:, :2] - kb[:, :2]).max() <= 4
-        assert abs(a_["score"] - b_["score"]) < 1e-2
+    # both runs execute the SAME kernel per layer shape (the first run saves its choice table, the second loads it and rank 0
+    # broadcasts it) and every batch has the same geometry, so the dumps must be EQUAL, not merely close
+    assert len(outs[0]) >= 10
+    assert outs[0] == outs[1]
+
+
+def test_evaluate_two_ranks_over_rccl_when_two_gpus_are_present(tmp_path):
+    """BASELINE configs[3] on the real collective: `evaluate.py --gpus 2` over the nccl backend (= RCCL) when the box has two GPUs
+    (an 8-GPU node runs this inside the GPU tier; a 1-GPU box skips it).  The dump must equal the 1-GPU run's."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import PKG
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    outs = []
+    for gpus in (1, 2):
+        dump = tmp_path / f"res{gpus}.json"
+        env = dict(os.environ)
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "POSEPAF_DIST_BACKEND"):
+            env.pop(k, None)
+        r = subprocess.run([sys.executable, os.path.join(PKG, "evaluate.py"), "--gpus", str(gpus), "--run_refactor", "--run_cpp",
+                            "--synthetic", "12", "--sizes", "256x256", "--batch", "2", "--people", "3", "--dump_name", str(dump)],
+                           capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        summary = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert summary["world"] == gpus and summary["images"] == 12 and summary["status_or"] == 0
+        outs.append(json.load(open(dump)))
+    assert outs[0] == outs[1]
+
+
+def test_evaluate_reads_a_coco_annotation_file_and_png_images(tmp_path):
+    """The reference's data path (evaluate.py:72, :237-279): annotation JSON + image files in, COCO-format results and the
+    keypoint AP against the ANNOTATION's ground truth out.  Offline there are no weights, so --inject_gt adds GT-style maps
+    rendered from the annotation's own keypoints to the (live) network output; the people found must match the annotation."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import PKG
+    from test_evaluate_sources_cpu import write_coco_fixture
+    ann, img_dir = write_coco_fixture(str(tmp_path))
+    dump = tmp_path / "res.json"
+    r = subprocess.run([sys.executable, os.path.join(PKG, "evaluate.py"), "--run_refactor", "--run_cpp", "--ann_file", ann,
+                        "--img_dir", img_dir, "--inject_gt", "--batch", "2", "--dump_name", str(dump)],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    summary = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert summary["images"] == 3 and summary["status_or"] == 0        # the image without a person annotation is not evaluated
+    res = json.load(open(dump))
+    assert {r_["image_id"] for r_ in res} <= {1000, 1007, 1014} and len(res) >= 4
+    assert all(len(r_["keypoints"]) == 51 and r_["category_id"] == 1 for r_ in res)
+    assert summary["keypoint_ap"]["AP"] > 0.5 and summary["keypoint_ap"]["n_gt"] >= 4, summary
+
+
+def test_ragged_preprocess_matches_the_per_image_padding():
+    """pp_preprocess_u8_ragged: images of different sizes in one padded bucket == utils/util.py:44-65 per image (pad 128 on the
+    bottom / right, / 255, mirror of the PADDED image); bytes outside an image's own area must not matter."""
+    import ctypes as C
+    from posepaf import _lib
+    from posepaf.pipeline import preprocess_batch
+    g = torch.Generator(device="cpu").manual_seed(11)
+    hp, wp, sizes = 128, 192, [(128, 192), (100, 150), (65, 129), (1, 1)]
+    slot = torch.randint(0, 256, (len(sizes), hp, wp, 3), dtype=torch.uint8, generator=g)       # garbage outside the images
+    dims = torch.tensor([[h for h, _ in sizes], [w for _, w in sizes]], dtype=torch.int32).cuda()
+    for dtype, code in ((torch.float16, _lib.PP_F16), (torch.float32, _lib.PP_F32)):
+        out = torch.empty((2 * len(sizes), hp, wp, 3), dtype=dtype, device="cuda")
+        _lib.check(_lib.load().pp_preprocess_u8_ragged(C.c_void_p(slot.cuda().data_ptr()), C.c_void_p(dims.data_ptr()),
+                                                       C.c_void_p(out.data_ptr()), code, len(sizes), hp, wp, 128, 1,
+                                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.synchronize()
+        for b, (h, w) in enumerate(sizes):
+            want = torch.full((hp, wp, 3), 128.0) / 255.0
+            want[:h, :w] = slot[b, :h, :w].float() / 255.0
+            assert torch.equal(out[2 * b].cpu(), want.to(dtype))
+            assert torch.equal(out[2 * b + 1].cpu(), want.flip(1).to(dtype))
+    # equal sizes: the ragged kernel == the equal-size kernel
+    imgs = slot[:, :128, :192].contiguous().cuda()
+    d2 = torch.tensor([[128] * 4, [192] * 4], dtype=torch.int32).cuda()
+    out = torch.empty((8, 128, 192, 3), dtype=torch.float16, device="cuda")
+    _lib.check(_lib.load().pp_preprocess_u8_ragged(C.c_void_p(imgs.data_ptr()), C.c_void_p(d2.data_ptr()), C.c_void_p(out.data_ptr()),
+                                                   _lib.PP_F16, 4, 128, 192, 128, 1, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    assert torch.equal(out, preprocess_batch(imgs, True, torch.float16))
 
 
 def test_util_keypoint_heatmap_nms_routes_to_the_hip_kernel():

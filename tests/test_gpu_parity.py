@@ -481,7 +481,6 @@ def test_original_multiscale_path_against_oracle(torch_cuda, oracle, people, dty
     assert np.array_equal(got_heat[0], got_heat[1])
     assert np.allclose(got_heat[0], heat, rtol=0, atol=1e-6) and np.allclose(got_paf[0], paf, rtol=0, atol=1e-6)
     assert np.array_equal(got_heat[0], heat) and np.array_equal(got_paf[0], paf)
-    recs = np.frombuffer(proc.finish(2).cpu().numpy().tobytes(), dtype=None) if False else None
     from posepaf.api import records_to_numpy
     recs = records_to_numpy(proc.finish(2))
     rows = oracle.find_peaks_original(heat, 0.1)
@@ -637,6 +636,42 @@ def test_status_words_after_graph_replay_at_bench_batch(torch_cuda, oracle):
         assert bool(eager[0][i]["status"] & 8) == bool(want["sort_oob"])
         if not want["sort_oob"]:
             _records_vs_oracle(eager[0][i], want, f"bench-mix image {i}")
+    post.close()
+
+
+def test_launch_structures_give_identical_records(torch_cuda):
+    """include/posepaf.h pp_debug_set_mode: "results are identical in every mode" -- 0 = assembly fused into the limb kernel's
+    last workgroup per image with load-ordered dispatch (the hand-rolled publish protocol: write-through stores, ticket,
+    acquire), 1 = assembly as its own launch (plain kernel boundary), 2 = fused without the ordering.  Eager and HIP-graph
+    replay, bench mix at B = 64: every record byte must agree across the three."""
+    from posepaf import synth
+    from posepaf.api import PosePostProcessor
+    torch = torch_cuda
+    B = 64
+    people = (1, 2, 3, 4, 5, 6, 8, 10, 12, 15, 20, 30, 2, 4, 6, 3)
+    post = PosePostProcessor(max_batch=B, max_h=128, max_w=128, max_peaks_per_part=64)
+    nets = torch.from_numpy(np.stack([synth.make_net_output(people[i % 16], 9000 + i % 16, dtype=np.float16) for i in range(B)])).cuda()
+    ref = None
+    for mode in (1, 0, 2):
+        post.set_mode(mode)
+        eager = post.process_async(nets, 512, True).cpu().numpy().copy()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            post.process_async(nets, 512, True)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = post.process_async(nets, 512, True)
+        for _ in range(3):
+            g.replay()
+        replay = out.cpu().numpy().copy()
+        assert np.array_equal(eager, replay), f"mode {mode}: eager != graph replay"
+        if ref is None:
+            ref = eager
+        assert np.array_equal(ref, eager), f"mode {mode} differs from the separate-launch structure"
+    post.set_mode(0)
     post.close()
 
 

@@ -51,3 +51,52 @@ def test_gt_from_synth_joints():
     for g in gt:
         kp = np.asarray(g["keypoints"]).reshape(17, 3)
         assert g["num_keypoints"] == int((kp[:, 2] > 0).sum()) and g["area"] > 0
+
+
+def test_crowd_and_unlabelled_ground_truth_are_ignored_not_counted():
+    """COCOeval: `ignore` = iscrowd or num_keypoints == 0 (cocoeval.py _prepare); a detection matched to an ignored GT is neither
+    TP nor FP, a crowd GT may absorb several detections, ignored GT do not count towards recall."""
+    from posepaf import oks_eval as oe
+    real, crowd = _gt(), dict(_gt(300, 300), iscrowd=1)
+    gts = {1: [crowd, real]}
+    dts = {1: [{"keypoints": real["keypoints"], "score": 0.9},
+               {"keypoints": crowd["keypoints"], "score": 0.8}, {"keypoints": crowd["keypoints"], "score": 0.7}]}
+    r = oe.evaluate_keypoints(gts, dts)
+    assert r["n_gt"] == 1 and abs(r["AP"] - 1.0) < 1e-9          # both crowd hits ignored: no false positive
+    # the same two extra detections far from everything ARE false positives, but rank below the true positive: AP stays 1
+    far = _gt(600, 600)["keypoints"]
+    r = oe.evaluate_keypoints({1: [real]}, {1: [dts[1][0], {"keypoints": far, "score": 0.8}]})
+    assert abs(r["AP"] - 1.0) < 1e-9
+    # ... and cap precision when they outrank it
+    r = oe.evaluate_keypoints({1: [real]}, {1: [{"keypoints": real["keypoints"], "score": 0.5}, {"keypoints": far, "score": 0.8}]})
+    assert abs(r["AP"] - 0.5) < 1e-9
+    # num_keypoints == 0: ignored; its OKS uses the distance to the doubled bounding box (0 inside)
+    blank = dict(_gt(300, 300), num_keypoints=0)
+    kp = np.asarray(blank["keypoints"]).reshape(17, 3).copy()
+    kp[:, 2] = 0
+    blank["keypoints"] = kp.reshape(-1).tolist()
+    d_in = np.asarray(_gt(300, 300)["keypoints"]).reshape(17, 3)
+    assert oe.compute_oks(d_in, kp, blank["area"], blank["bbox"]) == 1.0           # every joint inside the doubled box
+    d_out = d_in.copy()
+    d_out[:, 0] += 1000.0
+    assert oe.compute_oks(d_out, kp, blank["area"], blank["bbox"]) < 1e-6
+    r = oe.evaluate_keypoints({1: [real, blank]}, {1: [dts[1][0], {"keypoints": d_in.reshape(-1).tolist(), "score": 0.99}]})
+    assert r["n_gt"] == 1 and abs(r["AP"] - 1.0) < 1e-9
+
+
+def test_only_the_twenty_best_detections_per_image_count_and_area_comes_from_the_annotation():
+    from posepaf import oks_eval as oe
+    real = _gt()
+    far = _gt(600, 600)["keypoints"]
+    dts = {1: [{"keypoints": far, "score": 0.9 - 0.01 * i} for i in range(20)] + [{"keypoints": real["keypoints"], "score": 0.1}]}
+    r = oe.evaluate_keypoints({1: [real]}, dts)
+    assert r["n_dt"] == 20 and r["AP"] == 0.0                     # the true positive is the 21st: cut by maxDets = 20
+    # OKS scales with the ANNOTATION's area (segment area in COCO), not with the box
+    g = np.asarray(real["keypoints"]).reshape(17, 3)
+    d = g.copy()
+    d[:, 0] += 10
+    small, big = oe.compute_oks(d, g, 1000.0), oe.compute_oks(d, g, 100000.0)
+    assert small < big < 1.0
+    lo = oe.evaluate_keypoints({1: [dict(real, area=200.0)]}, {1: [{"keypoints": d.reshape(-1).tolist(), "score": 1.0}]})
+    hi = oe.evaluate_keypoints({1: [dict(real, area=1e6)]}, {1: [{"keypoints": d.reshape(-1).tolist(), "score": 1.0}]})
+    assert lo["AP"] < hi["AP"] and abs(hi["AP"] - 1.0) < 1e-9
