@@ -49,7 +49,7 @@ FLOP_PER_FORWARD_REFERENCE = 529.39e9                                   # SURVEY
 FLOP_PER_FORWARD_EXECUTED = 512.18e9                                    # tools/count_flops.py: the inference model (the last
 #                                                                         stage's unused coarse heads are not computed)
 FLOP_PER_IMAGE = 2 * FLOP_PER_FORWARD_EXECUTED                          # flip: two forwards per image
-ST_DEFINED, ST_SORT_UNDEFINED = 0x3F, 8                                 # include/posepaf.h:53-59
+ST_DEFINED, ST_SORT_UNDEFINED = 0x7F, 8                                 # include/posepaf.h:53-61
 
 
 def parse(argv=None):

@@ -23,7 +23,8 @@ struct pp_ctx {
     float4 *d_conns = nullptr;    // [max_batch][30][maxp] (cid1 bits, cid2 bits, score, length)
     int *d_conn_counts = nullptr; // [max_batch][30]
     float4 *d_conn_aux = nullptr; // [max_batch][30][maxp] (peak id 1, peak id 2, peak score 1, peak score 2): K_B -> assembly
-    int *d_sync = nullptr;        // [2 * max_batch + 16]: image order [max_batch] | per-image arrival tickets [max_batch] | K_A's
+    int *d_sync = nullptr;        // [32 * max_batch + 16]: image order [max_batch] | per-image launch counters [max_batch] | K_A's
+                                  // 16 words | per-limb publication flags [max_batch][30] (see k_limb_connect); then: K_A's
                                   // grid-wide ticket; zeroed ONCE here, re-armed by the kernels themselves (no memset node)
     int mode = 0;                 // pp_debug_set_mode
     unsigned *d_status = nullptr; // [max_batch][48] flag words, one per producing workgroup (posepaf_kernels.hip or_flags)
@@ -131,8 +132,8 @@ int pp_create(pp_ctx **out, int device, int max_batch, int max_h, int max_w, int
     if (e == hipSuccess) e = hipMalloc(&c->d_conns, B * PP_NUM_LIMB * c->maxp * sizeof(float4));
     if (e == hipSuccess) e = hipMalloc(&c->d_conn_counts, B * PP_NUM_LIMB * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&c->d_conn_aux, B * PP_NUM_LIMB * c->maxp * sizeof(float4));
-    if (e == hipSuccess) e = hipMalloc(&c->d_sync, (2 * B + 16) * sizeof(int));
-    if (e == hipSuccess) e = hipMemset(c->d_sync, 0, (2 * B + 16) * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&c->d_sync, (2 * B + 16 + PP_NUM_LIMB * B) * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(c->d_sync, 0, (2 * B + 16 + PP_NUM_LIMB * B) * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&c->d_conns_py, B * PP_NUM_LIMB * c->maxp * 32);
     if (e == hipSuccess) e = hipMalloc(&c->d_persons, 128 * 40 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&c->d_npersons, sizeof(int));
@@ -209,7 +210,8 @@ int pp_process_batch(pp_ctx *ctx, int batch, const void *net_out_dev, int dtype,
     PP_HIP(ctx, pp::launch_limb_connect(net_out_dev, dtype, batch, ns, h, w, flip, ctx->maxp, ctx->cap, min_img_size,
                                         min_img_size_dev, ctx->d_peaks, ctx->d_counts, ctx->d_conns, ctx->d_conn_aux,
                                         ctx->d_conn_counts, ctx->d_status, sorted ? order : nullptr,
-                                        ctx->mode == 1 ? nullptr : arrive, rec, st));
+                                        ctx->mode == 1 ? nullptr : arrive,
+                                        reinterpret_cast<unsigned *>(ctx->d_sync + 2 * ctx->max_batch + 16), rec, st));
     if (ctx->mode == 1)
         PP_HIP(ctx, pp::launch_assemble_wave(batch, ctx->maxp, ctx->d_peaks, ctx->d_counts, ctx->d_conns, ctx->d_conn_aux,
                                              ctx->d_conn_counts, ctx->d_status, rec, st));
@@ -275,7 +277,8 @@ int pp_time_kernels(pp_ctx *ctx, int batch, const void *net_out_dev, int dtype, 
                 PP_HIP(ctx, pp::launch_limb_connect(net_out_dev, dtype, batch, ns, h, w, flip, ctx->maxp, ctx->cap,
                                                     min_img_size, nullptr, ctx->d_peaks, ctx->d_counts, ctx->d_conns,
                                                     ctx->d_conn_aux, ctx->d_conn_counts, ctx->d_status,
-                                                    sorted ? order : nullptr, arrive, ctx->d_records, st));
+                                                    sorted ? order : nullptr, arrive,
+                                                    reinterpret_cast<unsigned *>(ctx->d_sync + 2 * ctx->max_batch + 16), ctx->d_records, st));
             } else {  // the assembly alone, one wave per image, as its own launch (diagnostic)
                 PP_HIP(ctx, pp::launch_assemble_wave(batch, ctx->maxp, ctx->d_peaks, ctx->d_counts, ctx->d_conns,
                                                      ctx->d_conn_aux, ctx->d_conn_counts, ctx->d_status, ctx->d_records, st));

@@ -26,12 +26,13 @@ hipError_t launch_heat_peaks(const void *net, int dtype, int batch, int n_sample
                              int nms_mode, float thr, int maxp, float4 *peaks, int *counts, unsigned *status, int *order,
                              int *arrive_all, hipStream_t stream);
 bool heat_peaks_sorts(int dtype, int batch, int h, int w, int maxp);
-// arrive != NULL: fused form, the last limb workgroup of each image assembles it into records (arrive[batch] zeroed once at
-// create, re-armed by the kernel); arrive == NULL: connections only (launch_assemble_wave follows).  order may be NULL.
+// arrive != NULL: fused form, workgroup 30 of each image assembles it into records WHILE its limbs are matched (arrive[batch]:
+// per-image launch counters, ready[batch][30]: per-limb publication flags; both zeroed once at create and owned by the kernel);
+// arrive == NULL: connections only (launch_assemble_wave follows).  order may be NULL.
 hipError_t launch_limb_connect(const void *net, int dtype, int batch, int n_samples, int h, int w, int flip, int maxp,
                                int cap, int min_img_size, const int *min_img_size_dev, const float4 *peaks,
                                const int *counts, float4 *conns, float4 *aux, int *conn_counts, unsigned *status,
-                               const int *order, int *arrive, pp_record *records, hipStream_t stream);
+                               const int *order, int *arrive, unsigned *ready, pp_record *records, hipStream_t stream);
 hipError_t launch_assemble_wave(int batch, int maxp, const float4 *peaks, const int *counts, const float4 *conns,
                                 const float4 *aux, const int *conn_counts, const unsigned *status, pp_record *records,
                                 hipStream_t stream);

@@ -22,6 +22,8 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "posepaf_internal.h"
 
 namespace pp {
@@ -51,8 +53,9 @@ __device__ const float d_cubic4[4][4] = {{-0.06591796875f, 0.42626953125f, 0.749
 // Diagnostic phase stamps (shader clock) written per workgroup when a stamp buffer is registered with
 // pp_debug_set_stamps(); a null pointer (the default) costs one scalar branch per phase.
 __device__ long long *d_stamps = nullptr;
+__device__ int d_stamp_realtime = 0;   // 1: the chip-wide 100 MHz counter (timelines across CUs) instead of the shader clock
 __device__ __forceinline__ void stamp(long long *buf, int wg, int slot) {
-    if (buf && threadIdx.x == 0) buf[(size_t)wg * 8 + slot] = (long long)clock64();
+    if (buf && threadIdx.x == 0) buf[(size_t)wg * 8 + slot] = d_stamp_realtime ? (long long)wall_clock64() : (long long)clock64();
 }
 
 constexpr int kThreads = 256;
@@ -123,7 +126,11 @@ __device__ __forceinline__ __half2 swap_h2(__half2 v) { return __lowhigh2highlow
 // flight per lane) -- the loop is latency-bound otherwise.
 constexpr int kLoadUnroll = 4;
 
-__device__ void load_channel(__half *smap, const __half *o0, const __half *o1, int h, int w, bool flip) {
+// NT = threads of the calling workgroup; ld = LDS row stride in elements (ld == w: dense; K_B pads every row by 16 bytes so
+// that equal columns of neighbouring rows fall into different banks -- its gathers run along near-vertical limbs).
+template <int NT = kThreads>
+__device__ void load_channel(__half *smap, const __half *o0, const __half *o1, int h, int w, bool flip, int ld = 0) {
+    if (ld == 0) ld = w;
     const int npix = h * w;
     const bool vec_ok = (w % 8 == 0) && ((reinterpret_cast<uintptr_t>(o0) & 15) == 0) &&
                         (!flip || (reinterpret_cast<uintptr_t>(o1) & 15) == 0);
@@ -132,11 +139,11 @@ __device__ void load_channel(__half *smap, const __half *o0, const __half *o1, i
         const int vpr = w / 8;  // vectors per row
         const uint4 *p0 = reinterpret_cast<const uint4 *>(o0);
         const uint4 *p1 = reinterpret_cast<const uint4 *>(o1);
-        for (int v0 = threadIdx.x; v0 < nvec; v0 += kThreads * kLoadUnroll) {
+        for (int v0 = threadIdx.x; v0 < nvec; v0 += NT * kLoadUnroll) {
             uint4 a[kLoadUnroll], m[kLoadUnroll];
 #pragma unroll
             for (int u = 0; u < kLoadUnroll; u++) {
-                const int v = v0 + u * kThreads;
+                const int v = v0 + u * NT;
                 if (v < nvec) {
                     a[u] = p0[v];
                     if (flip) {
@@ -147,7 +154,7 @@ __device__ void load_channel(__half *smap, const __half *o0, const __half *o1, i
             }
 #pragma unroll
             for (int u = 0; u < kLoadUnroll; u++) {
-                const int v = v0 + u * kThreads;
+                const int v = v0 + u * NT;
                 if (v < nvec) {
                     if (flip) {
                         __half2 *ah = reinterpret_cast<__half2 *>(&a[u]);
@@ -158,23 +165,24 @@ __device__ void load_channel(__half *smap, const __half *o0, const __half *o1, i
                         ah[2] = avg_h2(ah[2], swap_h2(mh[1]));
                         ah[3] = avg_h2(ah[3], swap_h2(mh[0]));
                     }
-                    reinterpret_cast<uint4 *>(smap)[v] = a[u];
+                    const int yy = v / vpr;
+                    reinterpret_cast<uint4 *>(smap)[yy * (ld / 8) + (v - yy * vpr)] = a[u];
                 }
             }
         }
     } else {
-        for (int i = threadIdx.x; i < npix; i += kThreads) {
+        for (int i = threadIdx.x; i < npix; i += NT) {
             __half a = o0[i];
-            if (flip) {
-                const int y = i / w, x = i - y * w;
-                a = __hmul(__hadd(a, o1[y * w + (w - 1 - x)]), __float2half(0.5f));
-            }
-            smap[i] = a;
+            const int y = i / w, x = i - y * w;
+            if (flip) a = __hmul(__hadd(a, o1[y * w + (w - 1 - x)]), __float2half(0.5f));
+            smap[y * ld + x] = a;
         }
     }
 }
 
-__device__ void load_channel(float *smap, const float *o0, const float *o1, int h, int w, bool flip) {
+template <int NT = kThreads>
+__device__ void load_channel(float *smap, const float *o0, const float *o1, int h, int w, bool flip, int ld = 0) {
+    if (ld == 0) ld = w;
     const int npix = h * w;
     const bool vec_ok = (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(o0) & 15) == 0) &&
                         (!flip || (reinterpret_cast<uintptr_t>(o1) & 15) == 0);
@@ -183,11 +191,11 @@ __device__ void load_channel(float *smap, const float *o0, const float *o1, int 
         const int vpr = w / 4;
         const float4 *p0 = reinterpret_cast<const float4 *>(o0);
         const float4 *p1 = reinterpret_cast<const float4 *>(o1);
-        for (int v0 = threadIdx.x; v0 < nvec; v0 += kThreads * kLoadUnroll) {
+        for (int v0 = threadIdx.x; v0 < nvec; v0 += NT * kLoadUnroll) {
             float4 a[kLoadUnroll], m[kLoadUnroll];
 #pragma unroll
             for (int u = 0; u < kLoadUnroll; u++) {
-                const int v = v0 + u * kThreads;
+                const int v = v0 + u * NT;
                 if (v < nvec) {
                     a[u] = p0[v];
                     if (flip) {
@@ -198,7 +206,7 @@ __device__ void load_channel(float *smap, const float *o0, const float *o1, int 
             }
 #pragma unroll
             for (int u = 0; u < kLoadUnroll; u++) {
-                const int v = v0 + u * kThreads;
+                const int v = v0 + u * NT;
                 if (v < nvec) {
                     if (flip) {
                         a[u].x = __fadd_rn(a[u].x, m[u].w) / 2.0f;
@@ -206,18 +214,17 @@ __device__ void load_channel(float *smap, const float *o0, const float *o1, int 
                         a[u].z = __fadd_rn(a[u].z, m[u].y) / 2.0f;
                         a[u].w = __fadd_rn(a[u].w, m[u].x) / 2.0f;
                     }
-                    reinterpret_cast<float4 *>(smap)[v] = a[u];
+                    const int yy = v / vpr;
+                    reinterpret_cast<float4 *>(smap)[yy * (ld / 4) + (v - yy * vpr)] = a[u];
                 }
             }
         }
     } else {
-        for (int i = threadIdx.x; i < npix; i += kThreads) {
+        for (int i = threadIdx.x; i < npix; i += NT) {
             float a = o0[i];
-            if (flip) {
-                const int y = i / w, x = i - y * w;
-                a = __fadd_rn(a, o1[y * w + (w - 1 - x)]) / 2.0f;
-            }
-            smap[i] = a;
+            const int y = i / w, x = i - y * w;
+            if (flip) a = __fadd_rn(a, o1[y * w + (w - 1 - x)]) / 2.0f;
+            smap[y * ld + x] = a;
         }
     }
 }
@@ -560,16 +567,22 @@ __global__ __launch_bounds__(kThreads) void k_heat_peaks(const T *__restrict__ n
 }
 
 // ------------------------------------------------------------------------------------------------ K_B
+// LDS row stride of K_B's limb map: the row length plus 16 bytes.  Lanes of a wave gather along near-vertical limbs (torso,
+// legs): with a dense 128-column map equal columns of ALL rows share a bank and those gathers serialise (44 % of the
+// kernel's LDS cycles were bank conflicts, profiles/r02_pmc_postproc_kernels.json); 16 bytes keep the vector stores aligned.
+template <typename T>
+__host__ __device__ constexpr int limb_map_ld(int w) { return w + 16 / (int)sizeof(T); }
+
 // Samplers.  Both return the value the reference reads at PAF(y, x, limb) (pafprocess.cpp:9, :322).
 template <typename T>
 struct LdsBicubicSampler {  // fused path: the (4h, 4w) upsample is never materialised
     const T *smap;
     const float *s_cub;
-    int h, w;
+    int h, w, ld;  // ld: LDS row stride in elements (>= w)
     __device__ __forceinline__ float at(int X, int Y) const {
         X = clampi(X, 0, 4 * w - 1);  // the reference does not bounds-check; in-range peaks never leave the map
         Y = clampi(Y, 0, 4 * h - 1);
-        return bicubic4_at(smap, w, 0, 0, w, h, X, Y, s_cub);
+        return bicubic4_at(smap, ld, 0, 0, w, h, X, Y, s_cub);
     }
 };
 struct GlobalHwcSampler {  // drop-in path: caller supplies the already up-sampled (H, W, C) map
@@ -871,12 +884,12 @@ __device__ inline LimbLds carve_limb_lds(unsigned char *p, int maxp, int cap) {
 //     candidate the sequential scan of :113-129 accepts; endpoints are then retired.  Ranks are distinct, so this
 //     yields the same set as the sequential greedy pick (and min(nA, nB) of :111 can never bind earlier).
 //  4. accepted connections written in rank order (the order the assembly consumes them in).
-template <typename Sampler>
-__device__ void connect_limb(const Sampler &smp, const LimbLds &L, int nA, int nB, int cap, int maxp, int min_img_size,
+template <typename Sampler, int NT = kThreads>
+__device__ int connect_limb(const Sampler &smp, const LimbLds &L, int nA, int nB, int cap, int maxp, int min_img_size,
                              float4 *__restrict__ conn_out, int *__restrict__ conn_count,
                              unsigned *__restrict__ status_word, long long *stamps = nullptr, int wg = 0,
                              float4 *__restrict__ aux_out = nullptr, int offA = 0, int offB = 0) {
-    __shared__ int s_wcnt[2][kWaves];
+    __shared__ int s_wcnt[2][(NT / 64)];
     __shared__ int s_stack[3 * kSortStack];
     __shared__ int s_oob;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -895,7 +908,7 @@ __device__ void connect_limb(const Sampler &smp, const LimbLds &L, int nA, int n
     int *sv_cnt = L.state;
     int nsv = 0;  // uniform
     auto flush = [&]() {
-        for (int sb = 0; sb < nsv; sb += kThreads, buf ^= 1) {
+        for (int sb = 0; sb < nsv; sb += NT, buf ^= 1) {
             const int sidx = sb + threadIdx.x;
             bool ok = false;
             float c2 = 0.f, overall = 0.f, len = 0.f;
@@ -917,7 +930,7 @@ __device__ void connect_limb(const Sampler &smp, const LimbLds &L, int nA, int n
             __syncthreads();
             int before = 0, all = 0;
 #pragma unroll
-            for (int k = 0; k < kWaves; k++) {
+            for (int k = 0; k < (NT / 64); k++) {
                 const int c = s_wcnt[buf][k];
                 if (k < wave) before += c;
                 all += c;
@@ -936,8 +949,113 @@ __device__ void connect_limb(const Sampler &smp, const LimbLds &L, int nA, int n
         __syncthreads();  // the survivor arrays may be overwritten from here on
         nsv = 0;
     };
-    for (int base = 0; base < npairs; base += kThreads, buf ^= 1) {
-        if (nsv + kThreads > cap) {
+    // Few pairs (most limbs of most images: P people give ~P * P pairs): one lane per pair leaves the wave a single chain of
+    // twenty dependent bicubic samples (~8 us for ANY number of pairs <= 256).  Below NT / 2 pairs the SAMPLES are spread over
+    // lanes instead -- eight lanes take the eight first samples of a pair, sixteen lanes the remaining twelve of a survivor --
+    // and the running sum is then formed by every lane of the group in the reference's order (s0 + s1 + ...; lanes past the
+    // pair's step count contribute +0.0f, the identity: a running sum that starts at +0.0f is never -0.0f).  Same values, same
+    // additions in the same order, a dependent chain five times shorter.
+    const bool sample_parallel = npairs <= NT / 2;
+    if (sample_parallel) {
+        constexpr int G1 = 8, PP1 = NT / G1;     // lanes per pair / pairs per round, first instalment
+        constexpr int G2 = 16, PP2 = NT / G2;    // second instalment: samples kFirst .. 19 (twelve of the sixteen lanes work)
+        static_assert(kFirst == G1 && 20 - kFirst <= G2, "lane groups cover the two instalments");
+        for (int base = 0; base < npairs; base += PP1, buf ^= 1) {
+            const int p = base + (int)(threadIdx.x / G1), j = threadIdx.x & (G1 - 1);
+            const int gl = lane & ~(G1 - 1);     // first lane of this pair's group
+            bool alive = false;
+            float scores = 0.0f, sj = 0.0f;
+            int k1 = 0, nsteps = 0;
+            if (p < npairs) {
+                const int ia = p / nB, ib = p - ia * nB;
+                PairGeom g;
+                if (pair_geom(L.ax[ia], L.ay[ia], L.bx[ib], L.by[ib], g)) {
+                    nsteps = g.num_steps;
+                    k1 = g.num_steps < kFirst ? g.num_steps : kFirst;
+                    if (j < k1) {
+                        int c_unused = 0;
+                        pair_samples(smp, g, L.ax[ia], L.ay[ia], j, j + 1, sj, c_unused);   // sj = 0 + s_j = s_j exactly
+                    }
+                }
+            }
+            const unsigned long long hit = __ballot(j < k1 && sj > 0.1f);
+#pragma unroll
+            for (int k = 0; k < G1; k++) scores = __fadd_rn(scores, __shfl(sj, gl + k));   // s_0 + s_1 + ... in order
+            const int c1 = __popcll((hit >> gl) & ((1ull << G1) - 1ull));
+            if (nsteps > 0) alive = (k1 - c1) <= nsteps - pair_min_count(nsteps);
+            const unsigned long long m = __ballot(alive && j == 0);
+            if (lane == 0) s_wcnt[buf][wave] = __popcll(m);
+            __syncthreads();
+            int before = 0, all = 0;
+#pragma unroll
+            for (int k = 0; k < (NT / 64); k++) {
+                const int c = s_wcnt[buf][k];
+                if (k < wave) before += c;
+                all += c;
+            }
+            if (alive && j == 0) {
+                const int pos = nsv + before + __popcll(m & lanemask_lt());
+                sv_pair[pos] = p;
+                sv_sum[pos] = scores;
+                sv_cnt[pos] = c1;
+            }
+            nsv += all;   // <= npairs <= NT / 2 <= cap: never flushed early
+        }
+        __syncthreads();
+        for (int sb = 0; sb < nsv; sb += PP2, buf ^= 1) {
+            const int sidx = sb + (int)(threadIdx.x / G2), j = threadIdx.x & (G2 - 1);
+            const int gl = lane & ~(G2 - 1);
+            bool ok = false;
+            float c2 = 0.f, overall = 0.f, len = 0.f, sj = 0.0f, scores = 0.0f;
+            int ia = 0, ib = 0, c1 = 0, nsteps = 0;
+            PairGeom g;
+            if (sidx < nsv) {
+                const int p = sv_pair[sidx];
+                ia = p / nB;
+                ib = p - ia * nB;
+                pair_geom(L.ax[ia], L.ay[ia], L.bx[ib], L.by[ib], g);
+                nsteps = g.num_steps;
+                scores = sv_sum[sidx];
+                c1 = sv_cnt[sidx];
+                if (kFirst + j < nsteps) {
+                    int c_unused = 0;
+                    pair_samples(smp, g, L.ax[ia], L.ay[ia], kFirst + j, kFirst + j + 1, sj, c_unused);
+                }
+            }
+            const unsigned long long hit = __ballot(kFirst + j < nsteps && sj > 0.1f);
+#pragma unroll
+            for (int k = 0; k < 20 - kFirst; k++) scores = __fadd_rn(scores, __shfl(sj, gl + k));
+            c1 += __popcll((hit >> gl) & ((1ull << G2) - 1ull));
+            if (sidx < nsv && j == 0) {
+                ok = pair_finish(g, scores, c1, L.as[ia], L.bs[ib], min_img_size, &c2, &overall);
+                len = g.vec_length;
+            }
+            const unsigned long long m = __ballot(ok);
+            if (lane == 0) s_wcnt[buf][wave] = __popcll(m);
+            __syncthreads();
+            int before = 0, all = 0;
+#pragma unroll
+            for (int k = 0; k < (NT / 64); k++) {
+                const int c = s_wcnt[buf][k];
+                if (k < wave) before += c;
+                all += c;
+            }
+            if (ok) {
+                const int pos = ncand + before + __popcll(m & lanemask_lt());
+                if (pos < cap) {
+                    L.key[pos] = overall;
+                    L.c_score[pos] = c2;
+                    L.c_len[pos] = len;
+                    L.c_idx[pos] = (unsigned)ia | ((unsigned)ib << 16);
+                }
+            }
+            ncand += all;
+        }
+        __syncthreads();
+        nsv = 0;
+    }
+    for (int base = 0; !sample_parallel && base < npairs; base += NT, buf ^= 1) {
+        if (nsv + NT > cap) {
             __syncthreads();  // the previous round's survivors (written by other waves) must be visible to flush()
             flush();
         }
@@ -960,7 +1078,7 @@ __device__ void connect_limb(const Sampler &smp, const LimbLds &L, int nA, int n
         __syncthreads();
         int before = 0, all = 0;
 #pragma unroll
-        for (int k = 0; k < kWaves; k++) {
+        for (int k = 0; k < (NT / 64); k++) {
             const int c = s_wcnt[buf][k];
             if (k < wave) before += c;
             all += c;
@@ -983,7 +1101,7 @@ __device__ void connect_limb(const Sampler &smp, const LimbLds &L, int nA, int n
     const int n = ncand;
     stamp(stamps, wg, 2);
     if (threadIdx.x == 0) s_oob = 0;
-    for (int i = threadIdx.x; i < maxp; i += kThreads) {
+    for (int i = threadIdx.x; i < maxp; i += NT) {
         L.usedA[i] = 0;
         L.usedB[i] = 0;
     }
@@ -991,7 +1109,7 @@ __device__ void connect_limb(const Sampler &smp, const LimbLds &L, int nA, int n
 
     // ---- 2. ranks (counting: gt = keys strictly greater, eq = keys equal incl. itself; 4 VALU per comparison pair)
     bool tie = false;
-    for (int t = threadIdx.x; t < n; t += kThreads) {
+    for (int t = threadIdx.x; t < n; t += NT) {
         const float kt = L.key[t];
         int gt = 0, eq = 0;
 #pragma unroll 4
@@ -1012,7 +1130,7 @@ __device__ void connect_limb(const Sampler &smp, const LimbLds &L, int nA, int n
     }
     const int any_tie = __syncthreads_or(tie);
     if (n > 16 && any_tie) {
-        for (int t = threadIdx.x; t < n; t += kThreads) L.order[t] = t;
+        for (int t = threadIdx.x; t < n; t += NT) L.order[t] = t;
         __syncthreads();
         if (wave == 0) {  // one wave; the preliminary ranks and the state array serve as its scratch
             LdsSortAcc acc{L.key, L.order};  // permuted in place: the generation-indexed keys are no longer needed
@@ -1026,10 +1144,10 @@ __device__ void connect_limb(const Sampler &smp, const LimbLds &L, int nA, int n
         // the array when nothing strictly greater precedes it, i.e. when key[p] >= max(key[0..p-1]): inclusive prefix
         // maxima by a doubling scan in the two scratch arrays.
         float *pm = reinterpret_cast<float *>(L.state), *pm2 = reinterpret_cast<float *>(L.rank);
-        for (int p = threadIdx.x; p < n; p += kThreads) pm[p] = L.key[p];
+        for (int p = threadIdx.x; p < n; p += NT) pm[p] = L.key[p];
         __syncthreads();
         for (int d = 1; d < n; d <<= 1) {
-            for (int p = threadIdx.x; p < n; p += kThreads) {
+            for (int p = threadIdx.x; p < n; p += NT) {
                 const float v = pm[p];
                 pm2[p] = p >= d ? fmaxf(v, pm[p - d]) : v;
             }
@@ -1039,9 +1157,9 @@ __device__ void connect_limb(const Sampler &smp, const LimbLds &L, int nA, int n
             pm2 = tmp;
         }
         bool oob = false;
-        for (int p = 16 + threadIdx.x; p < n; p += kThreads) oob |= L.key[p] >= pm[p - 1];
+        for (int p = 16 + threadIdx.x; p < n; p += NT) oob |= L.key[p] >= pm[p - 1];
         if (__syncthreads_or(oob) && threadIdx.x == 0) s_oob = 1;  // (barrier: the scratch arrays are rewritten below)
-        for (int p = threadIdx.x; p < n; p += kThreads) {
+        for (int p = threadIdx.x; p < n; p += NT) {
             const float kp = L.key[p];
             int gt = 0, eq = 0;
 #pragma unroll 4
@@ -1056,12 +1174,12 @@ __device__ void connect_limb(const Sampler &smp, const LimbLds &L, int nA, int n
             L.rank[L.order[p]] = gt + eq_after;
         }
         __syncthreads();
-        for (int t = threadIdx.x; t < n; t += kThreads) {
+        for (int t = threadIdx.x; t < n; t += NT) {
             L.order[L.rank[t]] = t;
             L.state[t] = 0;
         }
     } else {
-        for (int t = threadIdx.x; t < n; t += kThreads) L.order[L.rank[t]] = t;
+        for (int t = threadIdx.x; t < n; t += NT) L.order[L.rank[t]] = t;
     }
     __syncthreads();
     if (s_oob) st |= PP_ST_SORT_UNDEFINED;
@@ -1069,13 +1187,13 @@ __device__ void connect_limb(const Sampler &smp, const LimbLds &L, int nA, int n
     stamp(stamps, wg, 3);
     // ---- 3. greedy matching by local dominance
     for (int pass = 0; pass <= n; pass++) {  // every pass accepts at least the best live candidate: <= n passes
-        for (int i = threadIdx.x; i < maxp; i += kThreads) {
+        for (int i = threadIdx.x; i < maxp; i += NT) {
             L.minA[i] = 0x7fffffff;
             L.minB[i] = 0x7fffffff;
         }
         __syncthreads();
         bool live = false;
-        for (int t = threadIdx.x; t < n; t += kThreads) {
+        for (int t = threadIdx.x; t < n; t += NT) {
             if (L.state[t] == 0) {
                 const unsigned idx = L.c_idx[t];
                 const int ia = (int)(idx & 0xffffu), ib = (int)(idx >> 16);
@@ -1089,7 +1207,7 @@ __device__ void connect_limb(const Sampler &smp, const LimbLds &L, int nA, int n
             }
         }
         if (!__syncthreads_or(live)) break;
-        for (int t = threadIdx.x; t < n; t += kThreads) {
+        for (int t = threadIdx.x; t < n; t += NT) {
             if (L.state[t] == 0) {
                 const unsigned idx = L.c_idx[t];
                 const int ia = (int)(idx & 0xffffu), ib = (int)(idx >> 16);
@@ -1107,7 +1225,7 @@ __device__ void connect_limb(const Sampler &smp, const LimbLds &L, int nA, int n
     stamp(stamps, wg, 4);
     // ---- 4. ordered output
     int ncn = 0;
-    for (int base = 0; base < n; base += kThreads, buf ^= 1) {
+    for (int base = 0; base < n; base += NT, buf ^= 1) {
         const int r = base + threadIdx.x;
         bool acc = false;
         int t = 0;
@@ -1120,7 +1238,7 @@ __device__ void connect_limb(const Sampler &smp, const LimbLds &L, int nA, int n
         __syncthreads();
         int before = 0, all = 0;
 #pragma unroll
-        for (int k = 0; k < kWaves; k++) {
+        for (int k = 0; k < (NT / 64); k++) {
             const int c = s_wcnt[buf][k];
             if (k < wave) before += c;
             all += c;
@@ -1141,6 +1259,7 @@ __device__ void connect_limb(const Sampler &smp, const LimbLds &L, int nA, int n
         store_sc1(status_word, st);  // a store on every launch (no memset / atomic-OR protocol)
     }
     stamp(stamps, wg, 5);
+    return ncn;   // workgroup-uniform
 }
 
 // ------------------------------------------------------------------------------------------------ K_C, wave form
@@ -1516,16 +1635,28 @@ __device__ __forceinline__ void assemble_compact(const AsmWaveLds &A, int lane, 
 
 // Executed by all 64 lanes of ONE wave (lane = threadIdx.x & 63); `lds` holds assemble_wave_lds_bytes(maxp) bytes that no
 // other wave touches.  conns / aux: [30][maxp] of this image; cc_g: its 30 connection counts; cnt_g: its 18 peak counts.
+// STREAM: the limbs of the image are still being matched by other workgroups of the SAME launch.  Limb l may be read once
+// ready[l] carries this launch's tag in its upper 24 bits (the lower 8: its connection count); the wave polls with
+// agent-scope loads (bounded: PP_ST_SYNC_TIMEOUT), and looks one limb ahead so that a limb that is already published has
+// its connections in flight while the previous limb is assembled (see k_limb_connect for the publishing side).
+constexpr int kSpinMax = 1 << 18;
+__device__ __forceinline__ unsigned load_flag(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <bool STREAM>
 __device__ __forceinline__ void assemble_image_wave(int img, int lane, int maxp, const float4 *__restrict__ pk_g,
                                                     const int *__restrict__ cnt_g, const float4 *__restrict__ conns,
                                                     const float4 *__restrict__ aux, const int *__restrict__ cc_g,
                                                     const unsigned *__restrict__ flags, pp_record *__restrict__ rec,
-                                                    unsigned char *lds, long long *stamps) {
+                                                    unsigned char *lds, long long *stamps, const unsigned *ready = nullptr,
+                                                    unsigned want = 0) {
     const AsmWaveLds A = carve_asm_wave_lds(lds, maxp);
     stamp(stamps, img, 0);
     // ---- counts -> flat id offsets (pafprocess.cpp:43-48 flattens in part order); per-limb connection counts
     int pc = lane < PP_NUM_PART ? cnt_g[lane] : 0;
-    int cc = lane < PP_NUM_LIMB ? cc_g[lane] : 0;
+    int cc = (!STREAM && lane < PP_NUM_LIMB) ? cc_g[lane] : 0;
+    // STREAM: `snap` = a snapshot of the image's 30 flag words (lane l: limb l), one load; taken here (in flight while the
+    // tables are initialised) and again whenever a prefetch is issued
+    unsigned snap = (STREAM && lane < PP_NUM_LIMB) ? load_flag(ready + lane) : 0u;
     pc = pc < maxp ? pc : maxp;
     cc = cc < maxp ? cc : maxp;
     int inc = pc, cinc = cc;
@@ -1542,15 +1673,53 @@ __device__ __forceinline__ void assemble_image_wave(int img, int lane, int maxp,
     // prefetched connections (s_waitcnt vmcnt counts every vector memory operation of the wave)
     const int lpv = lane < PP_NUM_LIMB ? ((int)d_limb_pairs[lane][0] | ((int)d_limb_pairs[lane][1] << 8)) : 0;
     const int n_peaks = rl(inc, PP_NUM_PART - 1);
-    const int n_conn = rl(cinc, PP_NUM_LIMB - 1);
+    int n_conn = rl(cinc, PP_NUM_LIMB - 1);   // STREAM: summed up as the limbs arrive
     if (lane <= PP_NUM_PART) A.off[lane] = lane < PP_NUM_PART ? offv : n_peaks;
     // first limb's connections on their way while the table is initialised
-    const int m0 = rl(cc, 0);
+    const int m0 = STREAM ? 0 : rl(cc, 0);
     float4 pre_cn = make_float4(0.f, 0.f, 0.f, 0.f), pre_ax = pre_cn;
     if (lane < m0) {
         pre_cn = conns[lane];
         pre_ax = aux[lane];
     }
+    // STREAM: connections travel in UNITS -- one limb in the 64-lane layout (lane = connection), or up to eight consecutive
+    // published limbs with at most eight connections each in the wide layout (lane = 8 * limb + connection): a sparse image
+    // (most images) then costs four round trips to memory instead of thirty.  `cur` = the unit being assembled (blk_cn / blk_ax),
+    // `pf` = the unit in flight (pre_cn / pre_ax), chosen from the snapshot taken when the previous unit was issued.
+    int cur_first = 0, cur_end = 0, pf_first = 0, pf_n = 0;
+    bool cur_wide = false, pf_wide = false, sync_dead = false;
+    unsigned cur_fl = 0, pf_fl = 0;
+    float4 blk_cn = pre_cn, blk_ax = pre_cn;
+    auto issue_unit = [&](int start, unsigned fl) {   // fl: a snapshot; leaves pf_n = 0 when limb `start` is not published in it
+        pf_n = 0;
+        if (start >= PP_NUM_LIMB || sync_dead) return;
+        const unsigned long long pub = __ballot(lane < PP_NUM_LIMB && (fl >> 8) == want);
+        const unsigned long long sml = __ballot(lane < PP_NUM_LIMB && (fl & 0xffu) <= 8u);
+        if (!((pub >> start) & 1ull)) return;
+        int run = __builtin_ctzll(~((pub & sml) >> start));   // consecutive published limbs with <= 8 connections from `start`
+        run = run > 8 ? 8 : run;
+        pf_first = start;
+        pf_fl = fl;
+        if (run >= 2) {
+            pf_wide = true;
+            pf_n = run;
+            const int g = lane >> 3, idx = lane & 7;
+            const int l = start + (g < run ? g : 0);
+            const int ml = (int)(__shfl((int)fl, l) & 0xff);
+            if (g < run && idx < ml) {
+                pre_cn = conns[(size_t)l * maxp + idx];
+                pre_ax = aux[(size_t)l * maxp + idx];
+            }
+        } else {
+            pf_wide = false;
+            pf_n = 1;
+            const int ml = rl((int)fl, start) & 0xff;
+            if (lane < ml) {
+                pre_cn = conns[(size_t)start * maxp + lane];
+                pre_ax = aux[(size_t)start * maxp + lane];
+            }
+        }
+    };
     {  // every slot starts as an empty skeleton: ids -1, scores -1 (rows 18 / 19 are set at birth); lookup tables: tag 0
         int4 *qi = reinterpret_cast<int4 *>(A.sk_id);
         float4 *qf = reinterpret_cast<float4 *>(A.sk_sc);
@@ -1567,17 +1736,58 @@ __device__ __forceinline__ void assemble_image_wave(int img, int lane, int maxp,
 
     AsmState S{0, 0u, 0, 0, 0, 0};
     for (int limb = 0; limb < PP_NUM_LIMB; limb++) {
-        const int m = rl(cc, limb);
-        // this limb's connections were requested one limb ago: wait for them HERE, before the next request goes out, so that
-        // no later wait of this iteration has to cover the new request as well (vmcnt retires in order)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        float4 cur_cn = pre_cn, cur_ax = pre_ax;
-        asm volatile("" : "+v"(cur_cn.z), "+v"(cur_cn.w), "+v"(cur_ax.x), "+v"(cur_ax.y), "+v"(cur_ax.z), "+v"(cur_ax.w));
-        if (limb + 1 < PP_NUM_LIMB) {  // next limb's first 64 connections: in flight during this limb
-            const int mn = rl(cc, limb + 1);
-            if (lane < mn) {
-                pre_cn = conns[(size_t)(limb + 1) * maxp + lane];
-                pre_ax = aux[(size_t)(limb + 1) * maxp + lane];
+        int m;
+        float4 cur_cn, cur_ax;
+        if (STREAM) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the unit in flight (if any) and the snapshot have landed
+            if (limb >= cur_end) {
+                if (pf_n == 0 && !sync_dead) {   // nothing on its way: look until this limb is published, fetch, wait (the latency is
+                                                 // exposed only when the assembly has caught up with the matching)
+                    int spins = 0;
+                    while ((((unsigned)rl((int)snap, limb)) >> 8) != want) {
+                        if (++spins > kSpinMax) {
+                            sync_dead = true;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                        snap = lane < PP_NUM_LIMB ? load_flag(ready + lane) : 0u;
+                    }
+                    issue_unit(limb, snap);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                if (sync_dead) {   // give up: the remaining limbs count as empty, the record carries PP_ST_SYNC_TIMEOUT
+                    cur_first = limb, cur_end = PP_NUM_LIMB, cur_wide = false, cur_fl = 0u;
+                } else {
+                    blk_cn = pre_cn, blk_ax = pre_ax;
+                    asm volatile("" : "+v"(blk_cn.x), "+v"(blk_cn.y), "+v"(blk_cn.z), "+v"(blk_cn.w), "+v"(blk_ax.x), "+v"(blk_ax.y),
+                                 "+v"(blk_ax.z), "+v"(blk_ax.w));
+                    cur_first = pf_first, cur_end = pf_first + pf_n, cur_wide = pf_wide, cur_fl = pf_fl;
+                    issue_unit(cur_end, snap);   // the next unit (from the snapshot of one unit ago) flies while this one is assembled
+                    if (cur_end < PP_NUM_LIMB) snap = lane < PP_NUM_LIMB ? load_flag(ready + lane) : 0u;
+                }
+            }
+            m = rl((int)cur_fl, limb) & 0xff;
+            n_conn += m;
+            if (cur_wide) {   // this limb's connections sit in lanes 8 * (limb - cur_first) ...: bring them to lanes 0 ..
+                const int src = ((limb - cur_first) * 8 + lane) & 63;
+                cur_cn = make_float4(__shfl(blk_cn.x, src), __shfl(blk_cn.y, src), __shfl(blk_cn.z, src), __shfl(blk_cn.w, src));
+                cur_ax = make_float4(__shfl(blk_ax.x, src), __shfl(blk_ax.y, src), __shfl(blk_ax.z, src), __shfl(blk_ax.w, src));
+            } else {
+                cur_cn = blk_cn, cur_ax = blk_ax;
+            }
+        } else {
+            m = rl(cc, limb);
+            // this limb's connections were requested one limb ago: wait for them HERE, before the next request goes out, so
+            // that no later wait of this iteration has to cover the new request as well (vmcnt retires in order)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            cur_cn = pre_cn, cur_ax = pre_ax;
+            asm volatile("" : "+v"(cur_cn.z), "+v"(cur_cn.w), "+v"(cur_ax.x), "+v"(cur_ax.y), "+v"(cur_ax.z), "+v"(cur_ax.w));
+            if (limb + 1 < PP_NUM_LIMB) {  // next limb's first 64 connections: in flight during this limb
+                const int mn = rl(cc, limb + 1);
+                if (lane < mn) {
+                    pre_cn = conns[(size_t)(limb + 1) * maxp + lane];
+                    pre_ax = aux[(size_t)(limb + 1) * maxp + lane];
+                }
             }
         }
         if (m == 0) continue;
@@ -1679,6 +1889,7 @@ __device__ __forceinline__ void assemble_image_wave(int img, int lane, int maxp,
     if (lane == 0) {
         unsigned st = S.st;
         if (n_out > PP_MAX_HUMANS) st |= PP_ST_HUMAN_OVERFLOW;
+        if (sync_dead) st |= PP_ST_SYNC_TIMEOUT;
         rec->n_humans = n_rec;
         rec->n_peaks = n_peaks;
         rec->n_connections = n_conn;
@@ -1693,9 +1904,9 @@ __global__ __launch_bounds__(64, 3) void k_assemble_wave(int maxp, const float4 
                                                       pp_record *__restrict__ records) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int img = blockIdx.x;
-    assemble_image_wave(img, threadIdx.x, maxp, peaks + (size_t)img * PP_NUM_PART * maxp, counts + img * PP_NUM_PART,
-                        conns + (size_t)img * PP_NUM_LIMB * maxp, aux + (size_t)img * PP_NUM_LIMB * maxp,
-                        conn_counts + img * PP_NUM_LIMB, flags, records + img, lds_raw, d_stamps);
+    assemble_image_wave<false>(img, threadIdx.x, maxp, peaks + (size_t)img * PP_NUM_PART * maxp, counts + img * PP_NUM_PART,
+                               conns + (size_t)img * PP_NUM_LIMB * maxp, aux + (size_t)img * PP_NUM_LIMB * maxp,
+                               conn_counts + img * PP_NUM_LIMB, flags, records + img, lds_raw, d_stamps);
 }
 
 // K_B: LDS layout (dynamic): [map h*w T][cubic 16 f32][LimbLds: 40*maxp + 28*cap bytes]; the assembly tail re-uses the
@@ -1706,24 +1917,44 @@ __global__ __launch_bounds__(64, 3) void k_assemble_wave(int maxp, const float4 
 // workgroup barrier, one relaxed agent-scope ticket on arrive[img]); the workgroup that draws the last of
 // the 30 tickets re-arms the counter for the next launch, acquires, and its wave 0 assembles the image while the other
 // waves leave.  No workgroup ever waits for another one, so dispatch order and residency cannot deadlock it.
-template <typename T>
-__global__ __launch_bounds__(kThreads, 3) void k_limb_connect(const T *__restrict__ net, int n_samples, int h, int w,
+template <typename T, int NT>
+__global__ __launch_bounds__(NT, NT == 256 ? 3 : 4) void k_limb_connect(const T *__restrict__ net, int n_samples, int h, int w,
                                                            int flip, int maxp, int cap, int min_img_size,
                                                            const int *__restrict__ min_img_size_dev,
                                                            const float4 *__restrict__ peaks,
                                                            const int *__restrict__ counts, float4 *conns, float4 *aux,
                                                            int *conn_counts, unsigned *status, const int *__restrict__ order,
-                                                           int *arrive, pp_record *records) {
+                                                           int *arrive, unsigned *ready, pp_record *records) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     __shared__ int s_poff[PP_NUM_PART];
-    __shared__ int s_last;
     const int limb = blockIdx.x, img = order ? order[blockIdx.y] : blockIdx.y;
+    // Fused form (arrive != NULL): grid (31, B).  Workgroups 0..29 of an image match one limb each and PUBLISH it; workgroup 30
+    // is the image's ASSEMBLY: one wave that consumes limb 0, 1, ... as each is published (the assembly needs them in this
+    // order anyway, pafprocess.cpp:133), so it runs under the matching instead of after it.  arrive[img] is the image's
+    // launch counter (touched by this kernel only): every workgroup of the image reads it at its start, limb l publishes
+    // ready[img][l] = (counter + 1) << 8 | connection count, the assembly stores counter + 1 when it is done -- no flag is
+    // ever reset and a flag of an earlier launch can never be mistaken for this launch's.  The assembly workgroup has the
+    // HIGHEST index of its image: a workgroup is dispatched after every workgroup with a lower index of its XCD's queue, and
+    // limb workgroups never wait, so everything it waits for is running or done (its polling is bounded nevertheless).
+    const unsigned want = arrive ? (((unsigned)arrive[img] + 1u) & 0xffffffu) : 0u;
+    if (limb == PP_NUM_LIMB) {
+        if (threadIdx.x >= 64) return;
+        __builtin_amdgcn_s_setprio(3);   // a lone latency-bound instruction stream next to streaming waves
+        assemble_image_wave<true>(img, threadIdx.x, maxp, peaks + (size_t)img * PP_NUM_PART * maxp, counts + img * PP_NUM_PART,
+                                  conns + (size_t)img * PP_NUM_LIMB * maxp, aux + (size_t)img * PP_NUM_LIMB * maxp,
+                                  conn_counts + img * PP_NUM_LIMB, status, records + img, lds_raw,
+                                  d_stamps ? d_stamps + (size_t)gridDim.x * gridDim.y * 8 : nullptr,  // diagnostics: after the limbs'
+                                  ready + (size_t)img * PP_NUM_LIMB, want);
+        if (threadIdx.x == 0) store_sc1(arrive + img, (int)want);
+        return;
+    }
     const int pa = d_limb_pairs[limb][0], pb = d_limb_pairs[limb][1];
     int nA = counts[img * PP_NUM_PART + pa], nB = counts[img * PP_NUM_PART + pb];
     nA = nA < maxp ? nA : maxp;
     nB = nB < maxp ? nB : maxp;
     int *cc = conn_counts + img * PP_NUM_LIMB + limb;
     long long *stamps = d_stamps;
+    int ncn_out = 0;
     const int wg = blockIdx.y * gridDim.x + blockIdx.x;
     if (nA == 0 || nB == 0) {  // no candidate pairs: no connections (pafprocess.cpp:56-58, :111)
         if (threadIdx.x == 0) {
@@ -1731,10 +1962,10 @@ __global__ __launch_bounds__(kThreads, 3) void k_limb_connect(const T *__restric
             store_sc1(status + img * kFlagWords + PP_NUM_PART + limb, 0u);
         }
     } else {
-        const int npix = h * w;
+        const int ld = limb_map_ld<T>(w);   // padded LDS rows (see load_channel)
         size_t off = 0;
         T *smap = reinterpret_cast<T *>(lds_raw);
-        off += (sizeof(T) * (size_t)npix + 15) & ~(size_t)15;
+        off += (sizeof(T) * (size_t)h * ld + 15) & ~(size_t)15;
         float *s_cub = reinterpret_cast<float *>(lds_raw + off);
         off += 64;
         LimbLds L = carve_limb_lds(lds_raw + off, maxp, cap);
@@ -1753,52 +1984,39 @@ __global__ __launch_bounds__(kThreads, 3) void k_limb_connect(const T *__restric
         }
         const float4 *pka = peaks + ((size_t)img * PP_NUM_PART + pa) * maxp;
         const float4 *pkb = peaks + ((size_t)img * PP_NUM_PART + pb) * maxp;
-        for (int i = threadIdx.x; i < nA; i += kThreads) {
+        for (int i = threadIdx.x; i < nA; i += NT) {
             const float4 p = pka[i];
             L.ax[i] = (int)p.x;  // Peak.x/y are ints: truncation (pafprocess.cpp:35-36)
             L.ay[i] = (int)p.y;
             L.as[i] = p.z;
         }
-        for (int i = threadIdx.x; i < nB; i += kThreads) {
+        for (int i = threadIdx.x; i < nB; i += NT) {
             const float4 p = pkb[i];
             L.bx[i] = (int)p.x;
             L.by[i] = (int)p.y;
             L.bs[i] = p.z;
         }
-        const size_t plane = (size_t)npix;
+        const size_t plane = (size_t)h * w;
         const T *o0 = net + ((size_t)img * n_samples * PP_NUM_CH + limb) * plane;
         const T *o1 = net + (((size_t)img * n_samples + 1) * PP_NUM_CH + d_flip_paf_ord[limb]) * plane;
         stamp(stamps, wg, 0);
-        load_channel(smap, o0, o1, h, w, flip != 0);
+        load_channel<NT>(smap, o0, o1, h, w, flip != 0, ld);
         __syncthreads();
         stamp(stamps, wg, 1);
 
-        LdsBicubicSampler<T> smp{smap, s_cub, h, w};
+        LdsBicubicSampler<T> smp{smap, s_cub, h, w, ld};
         const int mis = min_img_size_dev ? min_img_size_dev[img] : min_img_size;
         const size_t row = ((size_t)img * PP_NUM_LIMB + limb) * maxp;
-        connect_limb(smp, L, nA, nB, cap, maxp, mis, conns + row, cc, status + img * kFlagWords + PP_NUM_PART + limb, stamps, wg,
+        ncn_out = connect_limb<LdsBicubicSampler<T>, NT>(smp, L, nA, nB, cap, maxp, mis, conns + row, cc, status + img * kFlagWords + PP_NUM_PART + limb, stamps, wg,
                      aux + row, s_poff[pa], s_poff[pb]);
     }
     if (!arrive) return;  // two-kernel form (timing / diagnostics): k_assemble_wave follows as its own launch
 
-    // ---- publish this limb, draw a ticket.  Everything the assembly reads from this workgroup was stored write-through
-    // (store_sc1), so there is no release fence: every storing wave drains, barrier, one lane draws the ticket.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // EVERY storing wave drains its stores
+    // ---- publish this limb.  Everything the assembly reads from this workgroup was stored write-through (store_sc1), so there
+    // is no release fence: EVERY storing wave drains its stores, the workgroup meets at a barrier, one lane stores the flag.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const int t = __hip_atomic_fetch_add(arrive + img, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = t == PP_NUM_LIMB - 1;
-        if (last) __hip_atomic_store(arrive + img, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
-        s_last = last;
-    }
-    __syncthreads();
-    if (!s_last || threadIdx.x >= 64) return;
-    // ---- the image is complete: wave 0 of this workgroup assembles it (the LDS region is free: every wave passed the barrier)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop this CU's stale L1 lines; this wave is the only reader
-    __builtin_amdgcn_s_setprio(3);                       // a lone latency-bound instruction stream next to streaming waves
-    assemble_image_wave(img, threadIdx.x, maxp, peaks + (size_t)img * PP_NUM_PART * maxp, counts + img * PP_NUM_PART,
-                        conns + (size_t)img * PP_NUM_LIMB * maxp, aux + (size_t)img * PP_NUM_LIMB * maxp,
-                        conn_counts + img * PP_NUM_LIMB, status, records + img, lds_raw, nullptr);
+    if (threadIdx.x == 0) store_sc1(ready + (size_t)img * PP_NUM_LIMB + limb, (want << 8) | (unsigned)ncn_out);
 }
 
 // Drop-in path: the caller's (H, W, C) up-sampled map lives in global memory (uploaded by process_paf)
@@ -2580,7 +2798,7 @@ __global__ __launch_bounds__(kThreads) void k_limb_connect_py(const T *__restric
     const T *o1 = net + (((size_t)img * n_samples + 1) * PP_NUM_CH + d_flip_paf_ord[limb]) * plane;
     load_channel(smap, o0, o1, h, w, flip != 0);
     __syncthreads();
-    LdsBicubicSampler<T> smp{smap, s_cub, h, w};
+    LdsBicubicSampler<T> smp{smap, s_cub, h, w, w};
     const int ih = img_height_dev ? img_height_dev[img] : img_height;
 
     connect_limb_py(smp, L, nA, nB, cap, maxp, ih, conns + ((size_t)img * PP_NUM_LIMB + limb) * maxp, cc,
@@ -3119,7 +3337,7 @@ size_t lds_bytes_heat(int elem, int h, int w, int maxp) {
     return ((elem * npix + 15) & ~(size_t)15) + 64 + ((4 * (size_t)maxp + 15) & ~(size_t)15) + ((npix + 7) / 8 + 15) / 16 * 16;
 }
 size_t lds_bytes_limb(int elem, int h, int w, int maxp, int cap) {
-    const size_t npix = (size_t)h * w;
+    const size_t npix = (size_t)h * (w + 16 / elem);   // padded rows: limb_map_ld
     const size_t limb = ((elem * npix + 15) & ~(size_t)15) + 64 + limb_lds_bytes(maxp, cap);
     const size_t tail = assemble_wave_lds_bytes(maxp);  // the last limb workgroup of an image assembles it in the same region
     return limb > tail ? limb : tail;
@@ -3130,6 +3348,10 @@ size_t lds_bytes_assemble(int maxp) { return assemble_lds_bytes(maxp); }
 // Dynamic LDS above the 64 KB default needs the attribute; set once per process (pp_create), not per launch, so
 // that the per-batch entry points stay free of anything but kernel launches (hipGraph-capturable).
 hipError_t set_stamp_buffer(long long *buf) {
+    const char *e = getenv("POSEPAF_STAMP_REALTIME");
+    const int rt = e && e[0] == '1';
+    hipError_t err = hipMemcpyToSymbol(HIP_SYMBOL(d_stamp_realtime), &rt, sizeof(rt));
+    if (err != hipSuccess) return err;
     return hipMemcpyToSymbol(HIP_SYMBOL(d_stamps), &buf, sizeof(buf));
 }
 
@@ -3137,8 +3359,10 @@ hipError_t init_kernel_attributes() {
     const int lim = (int)kMaxDynLds;
     const void *fns[] = {reinterpret_cast<const void *>(&k_heat_peaks<__half>),
                          reinterpret_cast<const void *>(&k_heat_peaks<float>),
-                         reinterpret_cast<const void *>(&k_limb_connect<__half>),
-                         reinterpret_cast<const void *>(&k_limb_connect<float>),
+                         reinterpret_cast<const void *>(&k_limb_connect<__half, 256>),
+                         reinterpret_cast<const void *>(&k_limb_connect<float, 256>),
+                         reinterpret_cast<const void *>(&k_limb_connect<__half, 512>),
+                         reinterpret_cast<const void *>(&k_limb_connect<float, 512>),
                          reinterpret_cast<const void *>(&k_limb_connect_hwc),
                          reinterpret_cast<const void *>(&k_assemble),
                          reinterpret_cast<const void *>(&k_assemble_wave),
@@ -3173,20 +3397,34 @@ bool heat_peaks_sorts(int dtype, int batch, int h, int w, int maxp) {
     return (size_t)batch * sizeof(int) <= lds_bytes_heat(dtype == PP_F16 ? 2 : 4, h, w, maxp);
 }
 
+// threads per limb workgroup: 256; POSEPAF_KB_THREADS=512 selects the 8-wave instance (A/B: 250 us against 182 us at 128 images
+// per launch -- two workgroups per CU instead of three cost more than the shorter scoring of the crowded limbs gains)
+int limb_threads() {
+    static const int nt = [] {
+        const char *e = getenv("POSEPAF_KB_THREADS");
+        return (e && atoi(e) == 512) ? 512 : 256;
+    }();
+    return nt;
+}
+
 hipError_t launch_limb_connect(const void *net, int dtype, int batch, int n_samples, int h, int w, int flip, int maxp,
                                int cap, int min_img_size, const int *min_img_size_dev, const float4 *peaks,
                                const int *counts, float4 *conns, float4 *aux, int *conn_counts, unsigned *status,
-                               const int *order, int *arrive, pp_record *records, hipStream_t stream) {
-    const dim3 grid(PP_NUM_LIMB, batch), block(kThreads);
+                               const int *order, int *arrive, unsigned *ready, pp_record *records, hipStream_t stream) {
+    const int nt = limb_threads();
+    const dim3 grid(PP_NUM_LIMB + (arrive ? 1 : 0), batch), block(nt);   // fused form: workgroup 30 of an image assembles it
     const size_t lds = lds_bytes_limb(dtype == PP_F16 ? 2 : 4, h, w, maxp, cap);  // >= the assembly tail's need
-    if (dtype == PP_F16)
-        hipLaunchKernelGGL(k_limb_connect<__half>, grid, block, lds, stream, static_cast<const __half *>(net), n_samples,
-                           h, w, flip, maxp, cap, min_img_size, min_img_size_dev, peaks, counts, conns, aux, conn_counts,
-                           status, order, arrive, records);
-    else
-        hipLaunchKernelGGL(k_limb_connect<float>, grid, block, lds, stream, static_cast<const float *>(net), n_samples, h,
-                           w, flip, maxp, cap, min_img_size, min_img_size_dev, peaks, counts, conns, aux, conn_counts, status,
-                           order, arrive, records);
+#define PP_LAUNCH_LIMB(T, NT)                                                                                                   \
+    hipLaunchKernelGGL((k_limb_connect<T, NT>), grid, block, lds, stream, static_cast<const T *>(net), n_samples, h, w, flip, maxp, \
+                       cap, min_img_size, min_img_size_dev, peaks, counts, conns, aux, conn_counts, status, order, arrive, ready, records)
+    if (dtype == PP_F16) {
+        if (nt == 512) PP_LAUNCH_LIMB(__half, 512);
+        else PP_LAUNCH_LIMB(__half, 256);
+    } else {
+        if (nt == 512) PP_LAUNCH_LIMB(float, 512);
+        else PP_LAUNCH_LIMB(float, 256);
+    }
+#undef PP_LAUNCH_LIMB
     return hipGetLastError();
 }
 

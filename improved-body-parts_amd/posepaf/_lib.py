@@ -15,7 +15,8 @@ MAX_HUMANS = 128
 PP_F32, PP_F16 = 0, 1
 
 ST_PEAK_OVERFLOW, ST_HUMAN_OVERFLOW, ST_SKEL_OVERFLOW, ST_SORT_UNDEFINED, ST_CAND_OVERFLOW, ST_FLOAT_COORDS = 1, 2, 4, 8, 16, 32
-ST_DEFINED_MASK = 0x3F            # include/posepaf.h:53-59; any other bit in pp_record.status is corruption
+ST_SYNC_TIMEOUT = 64
+ST_DEFINED_MASK = 0x7F            # include/posepaf.h:53-61; any other bit in pp_record.status is corruption
 ST_OVERFLOW_MASK = ST_PEAK_OVERFLOW | ST_HUMAN_OVERFLOW | ST_SKEL_OVERFLOW | ST_CAND_OVERFLOW
 
 # numpy views of pp_human / pp_record (include/posepaf.h)

@@ -57,6 +57,8 @@ typedef enum { PP_F32 = 0, PP_F16 = 1 } pp_dtype;
                                     would have read outside its array on this input: its result is undefined */
 #define PP_ST_CAND_OVERFLOW 16u  /* more accepted limb candidates for one limb than the kernel holds */
 #define PP_ST_FLOAT_COORDS 32u   /* original path: pp_human.x / .y hold float32 BIT PATTERNS (fractional coordinates) */
+#define PP_ST_SYNC_TIMEOUT 64u   /* the image's assembly gave up waiting for a limb of its own launch (cannot happen on a healthy
+                                    device: the record is incomplete and the context must be re-created) */
 
 /* One person.  Mirrors what evaluate.py:111-127 pulls through the getters:
  * peak_id[p] = get_part_peak_id(h,p) (-1 = part absent); x/y/part_score = get_part_x/y/score(peak_id);
