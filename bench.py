@@ -57,8 +57,8 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("POSEPAF_BENCH_BATCH", "128")),
-                    help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("POSEPAF_BENCH_BATCH", "0")),
+                    help="images per GPU per step (default 128; 32 with --multiscale)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="bound on the CPU baseline leg (all parts together)")
     ap.add_argument("--cpu-cores", type=int, default=0, help="worker processes of the CPU baseline (0 = every host core this process may use)")
@@ -70,7 +70,10 @@ def parse(argv=None):
     ap.add_argument("--no-verify", action="store_true", help="skip the independent re-computation of the last batch")
     ap.add_argument("--multiscale", action="store_true",
                     help="BASELINE configs[4]: original path, scale search {0.5, 1.0, 1.5} x 512 + flip, float64 accumulation")
-    return ap.parse_args(argv)
+    a = ap.parse_args(argv)
+    if a.batch <= 0:
+        a.batch = 32 if a.multiscale else 128
+    return a
 
 
 # ------------------------------------------------------------------------------------------------ self-launch
@@ -289,11 +292,29 @@ class GpuEngine:
                                    inject_scale=1e-3, max_image_hw=(IMG, IMG), n_slots=2, postproc_only=a.postproc_only,
                                    progress=say)
         if a.multiscale:
-            self.pipe = PosePipeline(self.model, self.post, dtype=torch.float16, flip=True)
             self.scale = torch.tensor(1e-3, dtype=torch.float16, device=dev)
             g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-            self.static_images = torch.randint(0, 256, (B, IMG, IMG, 3), dtype=torch.uint8, generator=g).to(dev)
+            self.ms_host = [torch.randint(0, 256, (B, IMG, IMG, 3), dtype=torch.uint8, generator=g).pin_memory() for _ in range(2)]
+            self.static_images = self.ms_host[0].to(dev)
             self._init_multiscale()
+            self.k = 0
+            self.ms_graph, self.ms_rec = None, None
+            with torch.no_grad():
+                for _ in range(2):                       # eager: tunes the three geometries of every convolution shape
+                    self._body_multiscale()
+            torch.cuda.synchronize()
+            if rank == 0 and not a.plain_model:
+                fused_model.save_table()
+            if not a.no_graph:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side), torch.no_grad():
+                    self._body_multiscale()
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                self.ms_graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.ms_graph), torch.no_grad():
+                    self.ms_rec = self._body_multiscale()
             return
         self.plan = self.eng.plan(IMG, IMG, B)
         self.eng.set_bank(self.plan, np.stack(self.uniq))
@@ -347,8 +368,46 @@ class GpuEngine:
             self.proc.accumulate(maps, 0, 0, len(self.ms_sizes))
         return self.proc.finish(self.B)
 
+    def _extras_multiscale(self, a, dt):
+        """roofline of the scale-accumulation kernel (k_accumulate_scales: every scale's flip-average, x4 bicubic, crop, resize and
+        the float64 accumulation in ONE launch) -- HIP events on the launch stream around that launch alone."""
+        torch = self.torch
+        B = a.batch
+        maps = [torch.addcmul(inj, torch.zeros_like(inj), self.scale) for inj in self.ms_inject]   # scene maps of the three scales
+        iters, ev = 10, [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        for k in range(iters + 2):
+            if k == 2:
+                ev[0].record()
+            self.proc.reset()
+            for m in maps:
+                self.proc.accumulate(m, 0, 0, len(maps))
+            self.proc._flush()
+        ev[1].record()
+        torch.cuda.synchronize()
+        ms = ev[0].elapsed_time(ev[1]) / iters
+        bytes_in = sum(m.numel() * m.element_size() for m in maps)                        # 2 * 50 * (64^2 + 128^2 + 192^2) * 2 B per image
+        bytes_out = B * 50 * IMG * IMG * 8                                                  # float64 accumulators, written once
+        alg = bytes_in + bytes_out
+        ach = alg / (ms * 1e-3) / 1e9
+        tf = B * a.steps * FLOP_PER_FORWARD_EXECUTED * 2 * (0.25 + 1.0 + 2.25) / dt / 1e12
+        return {"kernel_ms": {"k_accumulate_scales": ms},
+                "roofline": {"bound": "hbm", "kernel": "k_accumulate_scales", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg,
+                             "note": "network output of the three scales read once (fp16) + the 105 MB per image of float64 "
+                                     "accumulators written once; the kernel is bound by its bicubic arithmetic, not by HBM"},
+                "roofline_forward": {"bound": "mfma", "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                     "frac": tf / MFMA_F16_PEAK_TFLOPS,
+                                     "note": "three forwards per flip sample (inputs 256^2, 512^2, 768^2 = 3.5x the FLOPs of one 512^2 "
+                                             "forward) over the whole step time"}}
+
     def step(self):
         if self.a.multiscale:
+            if not self.a.no_ingest:   # the uint8 batch comes from pinned host memory every step (25 MB at 32 images)
+                self.static_images.copy_(self.ms_host[self.k % 2], non_blocking=True)
+                self.k += 1
+            if self.ms_graph is not None:
+                self.ms_graph.replay()
+                return self.ms_rec
             with self.torch.no_grad():
                 return self._body_multiscale()
         if self.a.no_ingest:
@@ -418,7 +477,7 @@ class GpuEngine:
         B = a.batch
         out = {}
         if a.multiscale:
-            return out
+            return self._extras_multiscale(a, dt)
         ms = self.post.time_kernels(self.inject, IMG, True, iters=20)
         # algorithmic bytes per launch: every flip sample of every channel the kernel consumes, fp16, once
         # the chain is two launches: k_heat_peaks (+ image ordering) and k_limb_connect (+ the person assembly by each image's
@@ -572,7 +631,7 @@ def main(argv=None):
                                     "pafprocess (NMS + limb line-integral + assembly)"),
                        "images_per_gpu_per_step": B, "people_per_scene": list(SCENE_PEOPLE),
                        "ingest": "off" if a.no_ingest else "pinned host -> HBM upload of each uint8 batch inside the step (copy stream, double-buffered)",
-                       "launch": "eager" if (a.no_graph or multi or stub) else "hipGraph replay",
+                       "launch": "eager" if (a.no_graph or stub) else "hipGraph replay",
                        "parallelism": f"image-sharded x{world}"},
             "humans_found_in_batch": humans, "status_or": status_or, "verify": verdict,
         }

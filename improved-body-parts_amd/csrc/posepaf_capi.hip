@@ -491,6 +491,24 @@ int pp_original_accumulate(pp_ctx *ctx, int batch, const void *net_out_dev, int 
     return PP_OK;
 }
 
+int pp_original_accumulate_all(pp_ctx *ctx, int batch, int n_scales, const void *const *net_out_dev, int dtype, const int *h,
+                               const int *w, int flip, const int *pad_down, const int *pad_right, int img_h, int img_w,
+                               double *heat_acc, double *paf_acc, void *stream) {
+    if (!ctx || !net_out_dev || !h || !w || !pad_down || !pad_right || !heat_acc || !paf_acc || batch <= 0 || img_h <= 0 ||
+        img_w <= 0 || n_scales <= 0 || (dtype != PP_F16 && dtype != PP_F32))
+        return PP_ERR_BAD_ARG;
+    if (n_scales > 6) return PP_ERR_UNSUPPORTED;
+    for (int i = 0; i < n_scales; i++)
+        if (!net_out_dev[i] || h[i] <= 0 || w[i] <= 0 || pad_down[i] < 0 || pad_right[i] < 0 || pad_down[i] >= 4 * h[i] ||
+            pad_right[i] >= 4 * w[i])
+            return PP_ERR_BAD_ARG;
+    const hipError_t e = pp::launch_accumulate_scales(n_scales, net_out_dev, dtype, batch, h, w, flip, pad_down, pad_right, img_h,
+                                                      img_w, heat_acc, paf_acc, static_cast<hipStream_t>(stream));
+    if (e == hipErrorInvalidValue) return PP_ERR_UNSUPPORTED;   // a scale whose tiles do not fit LDS: use pp_original_accumulate
+    PP_HIP(ctx, e);
+    return PP_OK;
+}
+
 int pp_original_finish(pp_ctx *ctx, int batch, int img_h, int img_w, float thre1, const double *heat_acc, const double *paf_acc,
                        unsigned char *mask_scratch, void *peaks64_scratch, pp_record *records_dev, void *stream) {
     if (!ctx || !heat_acc || !paf_acc || !mask_scratch || !peaks64_scratch || batch <= 0 || batch > ctx->max_batch ||

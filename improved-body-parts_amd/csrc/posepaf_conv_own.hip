@@ -137,6 +137,7 @@ __device__ __forceinline__ void epilogue_body(const float4_t (&acc)[PT][CT], con
 template <int PT, int CT, typename PixelOf>
 __device__ __forceinline__ void epilogue_store(const float4_t (&acc)[PT][CT], const ConvParams &p, int lane, int nbase,
                                                PixelOf pixel_of, bool do_store) {
+    if (nbase >= p.K) return;   // a wave whose 64 channels lie past C_out (halo kernel, C_out = 64 mod 128): wave-uniform
     // the residual mode is wave-uniform: three bodies, one scalar branch, no per-element selects
     if (p.mode == 0) epilogue_body<0, PT, CT>(acc, p, lane, nbase, pixel_of, do_store);
     else if (p.mode == 1) epilogue_body<1, PT, CT>(acc, p, lane, nbase, pixel_of, do_store);
@@ -382,7 +383,8 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     // is issued BEFORE the epilogue of the current tile: the output stores drain and the next operands arrive while the
     // epilogue computes, instead of store drain -> workgroup exit -> dispatch -> DMA latency in a row (a quarter of the time
     // of the non-persistent form).
-    const int nct = p.K / BN;
+    const int nct = (p.K + BN - 1) / BN;   // C_out = 64 mod 128: the upper half of the last tile has no channels (its weight
+                                           // rows read as zeros through the buffer bounds, its epilogue is skipped)
     const int ptiles = p.N * hp.tiles, per_xcd = (ptiles + 7) >> 3;
     const int total_ids = 8 * per_xcd * nct;
     const char *wb = reinterpret_cast<const char *>(p.w);
@@ -396,7 +398,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     // Wave w loads pieces w, w + 8, ..., w + 48 of every channel block (see the DMA schedule).
     int hsrc[7];   // byte offset inside the image for channel block 0, or -1: zero page (outside the image / past the halo)
     unsigned woff = 0; // weight sub-tile of this wave: 16 output channels x 32 halves per phase (lane part of the offset)
-    int bx_lo = 0, bx_hi = 0, bw_lo = 0, bw_hi = 0, nx = 0;   // buffer bases (this image / this wave's 16 weight rows) and the image's bytes
+    int bx_lo = 0, bx_hi = 0, bw_lo = 0, bw_hi = 0, nx = 0, bw_n = 0;   // buffer bases (this image / this wave's 16 weight rows) and the image's bytes
     auto rsrc_of = [&](int lo, int hi, int nbytes) {
         void *base = reinterpret_cast<void *>(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
         return __builtin_amdgcn_make_buffer_rsrc(base, 0, nbytes, 0x00020000);
@@ -435,6 +437,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
         bx_lo = __builtin_amdgcn_readfirstlane((int)(unsigned)ax), bx_hi = __builtin_amdgcn_readfirstlane((int)(unsigned)(ax >> 32));
         bw_lo = __builtin_amdgcn_readfirstlane((int)(unsigned)aw), bw_hi = __builtin_amdgcn_readfirstlane((int)(unsigned)(aw >> 32));
         nx = __builtin_amdgcn_readfirstlane((p.up ? p.H >> 1 : p.H) * sw_ * p.C * 2);
+        bw_n = __builtin_amdgcn_readfirstlane(n0 + wave * 16 < p.K ? 16 * 9 * p.C * 2 : 0);   // bytes of this wave's 16 weight rows
         return true;
     };
     auto next_tile = [&](int id) -> int {   // first valid id at or after `id` on this workgroup's stride, or total_ids
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     int st_slot = 0;
     int slot_cur = 0;            // ring slot of the phase being multiplied
     auto stage_w = [&]() {
-        lds_dma16_buf(rsrc_of(bw_lo, bw_hi, 16 * 9 * p.C * 2), woff, (unsigned)((st_tap * p.C + st_cb * 32) * 2), s_w + st_slot * WB + wave * SUB);
+        lds_dma16_buf(rsrc_of(bw_lo, bw_hi, bw_n), woff, (unsigned)((st_tap * p.C + st_cb * 32) * 2), s_w + st_slot * WB + wave * SUB);
         if (++st_slot == NW) st_slot = 0;
         if (++st_tap == 9) {
             st_tap = 0;
@@ -692,10 +695,11 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
 void *g_zero_page = nullptr;
 
 bool halo_geometry(const ConvParams &p, HaloParams &g) {
-    if (p.R != 3 || p.pad != 1 || p.dil != 1 || p.C % 32 || p.K % 128) return false;
+    if (p.R != 3 || p.pad != 1 || p.dil != 1 || p.C % 32 || p.K % 64) return false;   // K = 64 mod 128: the last channel tile is half empty
     if ((long)p.H * p.W * p.C * 2 >= (1L << 31)) return false;   // 32-bit byte offsets inside one image
-    int tw = p.W < 128 ? p.W : 128;
-    if (tw < 16 || (tw & (tw - 1)) || p.W % tw) return false;
+    int tw = 128;   // the widest power-of-two tile (<= 128) that divides the image width: 128, 64 (e.g. W = 192), 32 (96), 16 (48)
+    while (tw >= 16 && p.W % tw) tw >>= 1;
+    if (tw < 16) return false;
     const int th = TP / tw;
     if (p.H % th) return false;
     g.TW = tw;
@@ -723,7 +727,7 @@ int launch_halo_inst(const ConvParams &p, const HaloParams &g, hipStream_t st) {
         attr_done = true;
     }
     const unsigned ptiles = (unsigned)(p.N * g.tiles);
-    const unsigned ids = ((ptiles + 7) / 8) * 8 * (unsigned)(p.K / 128);   // 8 XCD ranges x ceil(ptiles / 8) x channel tiles
+    const unsigned ids = ((ptiles + 7) / 8) * 8 * (unsigned)((p.K + 127) / 128);   // 8 XCD ranges x ceil(ptiles / 8) x channel tiles
     static int ncu = 0;      // persistent grid: one workgroup per CU (160 KiB of LDS each), a multiple of 8
     static bool persist = true;
     if (ncu == 0) {

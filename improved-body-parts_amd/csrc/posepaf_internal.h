@@ -59,6 +59,9 @@ hipError_t launch_resize_cubic(const float *src, long src_plane, int src_ld, int
                                int dw, double scale_x, double scale_y, float n_div, hipStream_t stream);
 hipError_t launch_flip_average_planar(const void *net, int dtype, int batch, int h, int w, int flip, float *out,
                                       hipStream_t stream);
+hipError_t launch_accumulate_scales(int n_scales, const void *const *nets, int dtype, int batch, const int *hs, const int *ws,
+                                    int flip, const int *pad_down, const int *pad_right, int img_h, int img_w, double *heat_acc,
+                                    double *paf_acc, hipStream_t stream);
 hipError_t launch_fullres(int batch, int H, int W, float thre1, int maxp, int cap, int img_height, const double *heat_acc,
                           const double *paf_acc, unsigned char *mask_scratch, void *peaks64, int *counts, void *conns,
                           int *conn_counts, unsigned *status, pp_record *records, hipStream_t stream);

@@ -3184,6 +3184,157 @@ __global__ __launch_bounds__(256) void k_flip_average_planar(const T *__restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------ A10: all scales, one pass
+// predict's loop body for EVERY scale in one launch (utils/parse_skeletons.py:250-281): per output pixel of the image-sized
+// accumulator, for scale 1, 2, ...: flip-average -> x4 bicubic -> crop -> bicubic resize to the image -> acc += value / n
+// (float64, the reference's order), the accumulator living in a register until its ONE store.  The chain of round 2 wrote and
+// re-read a float32 copy of every up-sampled map (118 MB per image at scale 1.5) and read-modify-wrote the 105 MB of
+// accumulators once per scale: ~1 GB of HBM traffic per image against 23 MB of network output in and 105 MB out here.
+// Workgroup = a 32 x 32 tile of ONE channel of one image.  Per scale the tile's pre-images are staged in LDS: the rows/columns
+// of the cropped x4 map U its 4 x 4 taps reach, and the rows/columns of the flip-averaged network output A those reach.  Every
+// value is computed by the same expressions (cubic_coeffs, products and sums rounded separately, left to right) as
+// k_flip_average_planar / k_resize_cubic, so the accumulators are bit-identical to the chain's.
+constexpr int kAccTile = 32, kAccMaxScales = 6;
+struct AccScale {
+    const void *net;       // (B, 2|1, 50, h, w)
+    int h, w, ch, cw;      // map size; cropped size of its x4 up-sampling (4h - pad_down, 4w - pad_right)
+    int identity;          // the cropped map already has the image size: cv2.resize copies
+    double sx, sy;         // cw / img_w, ch / img_h
+};
+struct AccParams {
+    AccScale s[kAccMaxScales];
+    int n, flip, img_h, img_w, u_cap, a_cap;   // u_cap / a_cap: LDS tile capacities in elements
+    float n_div;
+    double *heat_acc, *paf_acc;
+};
+__device__ __forceinline__ int src_floor(int d, double scale) { return (int)floorf((float)(((double)d + 0.5) * scale - 0.5)); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_accumulate_scales(const AccParams P) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    float *sU = reinterpret_cast<float *>(lds_raw);
+    float *sA = sU + P.u_cap;
+    const int tiles_x = (P.img_w + kAccTile - 1) / kAccTile;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int oy0 = ty * kAccTile, ox0 = tx * kAccTile;
+    const int oy1 = min(oy0 + kAccTile, P.img_h), ox1 = min(ox0 + kAccTile, P.img_w);
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;   // this thread's output pixels: (oy0 + ly + 8 k, ox0 + lx)
+    const int ns = P.flip ? 2 : 1;
+    const int cf = c < PP_NUM_LIMB ? d_flip_paf_ord[c] : PP_NUM_LIMB + d_flip_heat_ord[c - PP_NUM_LIMB];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int si = 0; si < P.n; si++) {
+        const AccScale &S = P.s[si];
+        // ---- rows / columns of U the tile's taps reach, then rows / columns of A those reach (clamped like the taps are)
+        int ur0, ur1, uc0, uc1;
+        if (S.identity) {
+            ur0 = oy0, ur1 = oy1 - 1, uc0 = ox0, uc1 = ox1 - 1;
+        } else {
+            ur0 = clampi(src_floor(oy0, S.sy) - 1, 0, S.ch - 1), ur1 = clampi(src_floor(oy1 - 1, S.sy) + 2, 0, S.ch - 1);
+            uc0 = clampi(src_floor(ox0, S.sx) - 1, 0, S.cw - 1), uc1 = clampi(src_floor(ox1 - 1, S.sx) + 2, 0, S.cw - 1);
+        }
+        const int un = ur1 - ur0 + 1, um = uc1 - uc0 + 1;
+        const int ar0 = clampi(src_floor(ur0, 0.25) - 1, 0, S.h - 1), ar1 = clampi(src_floor(ur1, 0.25) + 2, 0, S.h - 1);
+        const int ac0 = clampi(src_floor(uc0, 0.25) - 1, 0, S.w - 1), ac1 = clampi(src_floor(uc1, 0.25) + 2, 0, S.w - 1);
+        const int an = ar1 - ar0 + 1, am = ac1 - ac0 + 1;
+        // ---- A tile: flip-average (utils/parse_skeletons.py:230-236) in the array's dtype, widened
+        const long plane = (long)S.h * S.w;
+        const T *o0 = static_cast<const T *>(S.net) + (((long)b * ns) * PP_NUM_CH + c) * plane;
+        const T *o1 = static_cast<const T *>(S.net) + (((long)b * ns + 1) * PP_NUM_CH + cf) * plane;
+        for (int i = threadIdx.x; i < an * am; i += 256) {
+            const int y = ar0 + i / am, x = ac0 + i % am;
+            float v;
+            if (sizeof(T) == 2) {
+                const __half *p0 = reinterpret_cast<const __half *>(o0), *p1 = reinterpret_cast<const __half *>(o1);
+                v = P.flip ? __half2float(__hmul(__hadd(p0[y * S.w + x], p1[y * S.w + (S.w - 1 - x)]), __float2half(0.5f)))
+                           : __half2float(p0[y * S.w + x]);
+            } else {
+                const float *p0 = reinterpret_cast<const float *>(o0), *p1 = reinterpret_cast<const float *>(o1);
+                v = P.flip ? __fadd_rn(p0[y * S.w + x], p1[y * S.w + (S.w - 1 - x)]) / 2.0f : p0[y * S.w + x];
+            }
+            sA[i] = v;
+        }
+        __syncthreads();
+        // ---- U tile: cv2.resize(fx = fy = 4, INTER_CUBIC) of A (:252-263), taps clamped to the map
+        for (int i = threadIdx.x; i < un * um; i += 256) {
+            const int uy = ur0 + i / um, ux = uc0 + i % um;
+            float fx = (float)(((double)ux + 0.5) * 0.25 - 0.5);
+            const int sx = (int)floorf(fx);
+            fx = __fadd_rn(fx, -(float)sx);
+            float fy = (float)(((double)uy + 0.5) * 0.25 - 0.5);
+            const int sy = (int)floorf(fy);
+            fy = __fadd_rn(fy, -(float)sy);
+            float ca[4], cb[4];
+            cubic_coeffs(fx, ca);
+            cubic_coeffs(fy, cb);
+            const int x0 = clampi(sx - 1, 0, S.w - 1) - ac0, x1 = clampi(sx, 0, S.w - 1) - ac0, x2 = clampi(sx + 1, 0, S.w - 1) - ac0,
+                      x3 = clampi(sx + 2, 0, S.w - 1) - ac0;
+            float hrow[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float *row = sA + (clampi(sy - 1 + k, 0, S.h - 1) - ar0) * am;
+                float hv = __fmul_rn(row[x0], ca[0]);
+                hv = __fadd_rn(hv, __fmul_rn(row[x1], ca[1]));
+                hv = __fadd_rn(hv, __fmul_rn(row[x2], ca[2]));
+                hv = __fadd_rn(hv, __fmul_rn(row[x3], ca[3]));
+                hrow[k] = hv;
+            }
+            float v = __fmul_rn(hrow[0], cb[0]);
+            v = __fadd_rn(v, __fmul_rn(hrow[1], cb[1]));
+            v = __fadd_rn(v, __fmul_rn(hrow[2], cb[2]));
+            v = __fadd_rn(v, __fmul_rn(hrow[3], cb[3]));
+            sU[i] = v;
+        }
+        __syncthreads();
+        // ---- crop (:272-273), resize to the image size (:276-277), += value / n in float64 (:280-281)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int dy = oy0 + ly + 8 * k, dx = ox0 + lx;
+            if (dy < oy1 && dx < ox1) {
+                float v;
+                if (S.identity) {
+                    v = sU[(dy - ur0) * um + (dx - uc0)];
+                } else {
+                    float fx = (float)(((double)dx + 0.5) * S.sx - 0.5);
+                    const int sx = (int)floorf(fx);
+                    fx = __fadd_rn(fx, -(float)sx);
+                    float fy = (float)(((double)dy + 0.5) * S.sy - 0.5);
+                    const int sy = (int)floorf(fy);
+                    fy = __fadd_rn(fy, -(float)sy);
+                    float ca[4], cb[4];
+                    cubic_coeffs(fx, ca);
+                    cubic_coeffs(fy, cb);
+                    const int x0 = clampi(sx - 1, 0, S.cw - 1) - uc0, x1 = clampi(sx, 0, S.cw - 1) - uc0,
+                              x2 = clampi(sx + 1, 0, S.cw - 1) - uc0, x3 = clampi(sx + 2, 0, S.cw - 1) - uc0;
+                    float hrow[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float *row = sU + (clampi(sy - 1 + r, 0, S.ch - 1) - ur0) * um;
+                        float hv = __fmul_rn(row[x0], ca[0]);
+                        hv = __fadd_rn(hv, __fmul_rn(row[x1], ca[1]));
+                        hv = __fadd_rn(hv, __fmul_rn(row[x2], ca[2]));
+                        hv = __fadd_rn(hv, __fmul_rn(row[x3], ca[3]));
+                        hrow[r] = hv;
+                    }
+                    v = __fmul_rn(hrow[0], cb[0]);
+                    v = __fadd_rn(v, __fmul_rn(hrow[1], cb[1]));
+                    v = __fadd_rn(v, __fmul_rn(hrow[2], cb[2]));
+                    v = __fadd_rn(v, __fmul_rn(hrow[3], cb[3]));
+                }
+                acc[k] = __dadd_rn(acc[k], (double)(v / P.n_div));
+            }
+        }
+        __syncthreads();   // the tiles are rewritten by the next scale
+    }
+    double *D = c < PP_NUM_LIMB ? P.paf_acc + ((long)b * PP_NUM_LIMB + c) * P.img_h * P.img_w
+                                : P.heat_acc + ((long)b * PP_NUM_HEAT + (c - PP_NUM_LIMB)) * P.img_h * P.img_w;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int dy = oy0 + ly + 8 * k, dx = ox0 + lx;
+        if (dy < oy1 && dx < ox1) D[(long)dy * P.img_w + dx] = acc[k];
+    }
+}
+
 // find_peaks at image resolution: one workgroup per (part, image).  The float64 accumulator is cast to float32 on read
 // (:290); 3x3 / >= thre NMS (reflect padding == ignore out-of-map neighbours); np.nonzero order via per-thread contiguous
 // pixel ranges + block scan; refine_centroid per peak.  peaks: double4 (x, y, score, id-unused).
@@ -3511,6 +3662,47 @@ hipError_t launch_flip_average_planar(const void *net, int dtype, int batch, int
     else
         hipLaunchKernelGGL(k_flip_average_planar<float>, dim3(blocks), dim3(256), 0, stream, static_cast<const float *>(net),
                            batch, h, w, flip, out);
+    return hipGetLastError();
+}
+
+// One launch for all scales; PP_ERR-like failure (hipErrorInvalidValue) when a scale's tiles do not fit LDS (the caller then
+// uses the per-scale chain).  nets[i]: (batch, 2|1, 50, hs[i], ws[i]).
+hipError_t launch_accumulate_scales(int n_scales, const void *const *nets, int dtype, int batch, const int *hs, const int *ws,
+                                    int flip, const int *pad_down, const int *pad_right, int img_h, int img_w, double *heat_acc,
+                                    double *paf_acc, hipStream_t stream) {
+    if (n_scales < 1 || n_scales > kAccMaxScales) return hipErrorInvalidValue;
+    AccParams P;
+    P.n = n_scales;
+    P.flip = flip;
+    P.img_h = img_h;
+    P.img_w = img_w;
+    P.n_div = (float)n_scales;
+    P.heat_acc = heat_acc;
+    P.paf_acc = paf_acc;
+    int umax = 0, amax = 0;
+    for (int i = 0; i < n_scales; i++) {
+        AccScale &S = P.s[i];
+        S.net = nets[i];
+        S.h = hs[i];
+        S.w = ws[i];
+        S.ch = 4 * hs[i] - pad_down[i];
+        S.cw = 4 * ws[i] - pad_right[i];
+        if (S.ch <= 0 || S.cw <= 0) return hipErrorInvalidValue;
+        S.identity = (S.ch == img_h && S.cw == img_w) ? 1 : 0;
+        S.sx = 1.0 / ((double)img_w / (double)S.cw);
+        S.sy = 1.0 / ((double)img_h / (double)S.ch);
+        const int ur = S.identity ? kAccTile : (int)(kAccTile * S.sy) + 6, uc = S.identity ? kAccTile : (int)(kAccTile * S.sx) + 6;
+        const int ar = ur / 4 + 6, ac = uc / 4 + 6;
+        umax = ur * uc > umax ? ur * uc : umax;
+        amax = ar * ac > amax ? ar * ac : amax;
+    }
+    P.u_cap = umax;
+    P.a_cap = amax;
+    const size_t lds = ((size_t)umax + amax) * sizeof(float);
+    if (lds > 60000) return hipErrorInvalidValue;
+    const dim3 grid(((img_w + kAccTile - 1) / kAccTile) * ((img_h + kAccTile - 1) / kAccTile), PP_NUM_CH, batch);
+    if (dtype == PP_F16) hipLaunchKernelGGL(k_accumulate_scales<__half>, grid, dim3(256), lds, stream, P);
+    else hipLaunchKernelGGL(k_accumulate_scales<float>, grid, dim3(256), lds, stream, P);
     return hipGetLastError();
 }
 

@@ -278,6 +278,14 @@ PP_API uint32_t pp_get_status(const pp_ctx *ctx);
 PP_API int pp_original_accumulate(pp_ctx *ctx, int batch, const void *net_out_dev, int dtype, int h, int w, int flip,
                                   int pad_down, int pad_right, int img_h, int img_w, int n_scales, float *scratch_planar,
                                   float *scratch_up, double *heat_acc, double *paf_acc, void *stream);
+/* All scales of predict's loop in ONE launch: the accumulators are WRITTEN (not added to; no zeroing needed) with
+ * ((0 + v_1 / n) + v_2 / n) + ... in float64, bit-identical to n_scales calls of pp_original_accumulate on zeroed accumulators,
+ * without the scratch maps and without re-reading the accumulators per scale.  net_out_dev[i]: DEVICE (batch, 2|1, 50, h[i],
+ * w[i]); h / w / pad_down / pad_right: HOST arrays of n_scales entries (n_scales <= 6).  PP_ERR_UNSUPPORTED when a scale is so
+ * large that its tiles do not fit LDS (more than ~3x the image size): use the per-scale form then. */
+PP_API int pp_original_accumulate_all(pp_ctx *ctx, int batch, int n_scales, const void *const *net_out_dev, int dtype, const int *h,
+                                      const int *w, int flip, const int *pad_down, const int *pad_right, int img_h, int img_w,
+                                      double *heat_acc, double *paf_acc, void *stream);
 PP_API int pp_original_finish(pp_ctx *ctx, int batch, int img_h, int img_w, float thre1, const double *heat_acc,
                               const double *paf_acc, unsigned char *mask_scratch, void *peaks64_scratch, pp_record *records_dev,
                               void *stream);

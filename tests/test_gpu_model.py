@@ -275,6 +275,10 @@ def test_own_implicit_gemm_convolution_matches_torch(shape):
     (2, 32, 384, 8, 256),       # 256-wide image: two 4 x 128 tiles per row pair; one channel block (no halo prefetch)
     (9, 64, 256, 64, 128),      # 288 workgroup ids on a 256-workgroup persistent grid: 32 workgroups walk two tiles
     (131, 32, 128, 32, 32),     # 262 pixel tiles: 33 per XCD range with two padding ids, second tiles on 8 workgroups only
+    (2, 64, 128, 16, 192),      # width 192 (the 768-pixel input of the scale search): three 8 x 64 tiles per row band
+    (1, 64, 256, 32, 96),       # width 96: three 16 x 32 tiles per row band
+    (1, 64, 192, 32, 64),       # C_out = 64 mod 128: the second channel tile is half empty (zero weight rows, epilogue skipped)
+    (2, 32, 64, 16, 128),       # C_out = 64: one half-empty channel tile
 ])
 def test_halo_tile_3x3_convolution_matches_torch(shape):
     """pp_conv_own_f16 with bn = 512: the 3x3 kernel that keeps the input halo of a 512-pixel tile in LDS and reads the nine
@@ -318,6 +322,7 @@ def test_halo_tile_3x3_convolution_matches_torch(shape):
     (2, 64, 128, 16, 16),       # 32-wide tiles
     (1, 128, 256, 8, 64),       # 128-wide tiles, two output-channel tiles
     (3, 32, 128, 32, 32),       # 64-wide tiles, one channel block
+    (1, 64, 128, 8, 96),        # 192-wide output (three 64-wide tiles) read from a 96-wide half-resolution input
 ])
 def test_halo_kernel_upsampled_input_and_two_post_adds(shape):
     """pp_conv_own_ex_f16: the x2 nearest upsample (models/layers_transposed.py:212, :272) read through the 3x3 kernel's halo loads

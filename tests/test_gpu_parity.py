@@ -639,6 +639,35 @@ def test_status_words_after_graph_replay_at_bench_batch(torch_cuda, oracle):
     post.close()
 
 
+def test_fused_scale_accumulation_equals_the_per_scale_chain(torch_cuda):
+    """pp_original_accumulate_all (one launch, accumulators written once) against n calls of pp_original_accumulate (x4 map in
+    HBM, read-modify-write per scale): bit-identical float64 accumulators -- ragged image size (tiles cut at the border),
+    padded inputs (crop), a down-scaling, an identity and an up-scaling resize, fp16 and fp32 maps, flip on and off."""
+    from posepaf import synth
+    from posepaf.api import PosePostProcessor
+    from posepaf.original_path import OriginalPathProcessor
+    torch = torch_cuda
+    H, W = 200, 264                                       # image; scales 0.5 / 1.0 / 1.5 -> 100x132, 200x264, 300x396
+    sizes = [(32, 48, 0.5), (64, 80, 1.0), (80, 112, 1.5)]   # maps of the inputs padded to /64: 128x192, 256x320, 320x448
+    pads = [(128 - 100, 192 - 132), (256 - 200, 320 - 264), (320 - 300, 448 - 396)]
+    post = PosePostProcessor(max_batch=2, max_h=80, max_w=112, max_peaks_per_part=64)
+    for dtype in (np.float16, np.float32):
+        for flip in (True, False):
+            g = np.random.default_rng(7)
+            maps = [torch.from_numpy((g.random((2, 2 if flip else 1, 50, h, w)) * 0.8).astype(dtype)).cuda() for h, w, _ in sizes]
+            res = []
+            for fused in (True, False):
+                proc = OriginalPathProcessor(post, H, W, 2)
+                proc.fused = fused
+                proc.reset()
+                for m, (pd, pr) in zip(maps, pads):
+                    proc.accumulate(m, pd, pr, len(sizes), flip=flip)
+                res.append((proc.heat_acc.clone(), proc.paf_acc.clone()))
+            assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), (dtype, flip)
+            assert float(res[0][1].abs().max()) > 0.1
+    post.close()
+
+
 def test_launch_structures_give_identical_records(torch_cuda):
     """include/posepaf.h pp_debug_set_mode: "results are identical in every mode" -- 0 = assembly fused into the limb kernel's
     last workgroup per image with load-ordered dispatch (the hand-rolled publish protocol: write-through stores, ticket,

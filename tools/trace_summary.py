@@ -2,7 +2,9 @@
 """Reduce a rocprofv3 --kernel-trace CSV of bench.py to the per-kernel totals of ONE steady-state step
 (the window between the last two k_heat_peaks launches of the timed loop) and print/save a small CSV.
 
-    python tools/trace_summary.py <dir with *_kernel_trace.csv> <out.csv> [--delete-trace]
+    python tools/trace_summary.py <dir with *_kernel_trace.csv> <out.csv> [--delete-trace] [--anchor=KERNEL_SUBSTRING]
+
+(rocprofv3 of ROCm 7 writes a database by default: pass --output-format csv to it.)
 """
 import collections
 import csv
@@ -17,7 +19,8 @@ with open(f) as fh:
     for r in csv.DictReader(fh):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-hp = [i for i, r in enumerate(rows) if "k_heat_peaks" in r[2]]
+anchor = ([a.split("=", 1)[1] for a in sys.argv if a.startswith("--anchor=")] or ["k_heat_peaks"])[0]
+hp = [i for i, r in enumerate(rows) if anchor in r[2]]
 # A steady-state step of bench.py is a graph replay: the windows between consecutive K_A launches that hold the MOST COMMON
 # kernel count among the big ones (warm-up passes tune and hold many more kernels; pp_time_kernels / verify windows hold few).
 sizes = [hp[i + 1] - hp[i] for i in range(len(hp) - 1)]
