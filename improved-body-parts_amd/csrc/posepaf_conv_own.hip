@@ -20,6 +20,7 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstdlib>
 #include <type_traits>
@@ -691,8 +692,40 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
         for (int k = 0; k < 6; k++) g_conv_clk[blockIdx.x * 8 + k] = acc_t[k];
 }
 
+// Per-DEVICE lazily initialised state (a process may hold contexts on several GPUs): the zero page the implicit-GEMM kernel
+// reads out-of-image taps from, the CU count of the persistent grid, and which kernel instances have had their dynamic-LDS
+// attribute raised on that device.  Indexed by hipGetDevice(); initialisation allocates, so it refuses to run inside a stream
+// capture (PP_ERR_UNSUPPORTED: call the entry point once eagerly first, as every warm-up does).
+constexpr int kMaxDevices = 32, kMaxInst = 24;
+struct DevState {
+    void *zero = nullptr;
+    int ncu = 0;
+    bool attr[kMaxInst] = {};
+};
+DevState g_dev[kMaxDevices];
+std::atomic<int> g_inst_count{0};   // instance ids handed out to the launch templates (one per instantiation)
+
+DevState *dev_state() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+    return &g_dev[dev];
+}
+bool capturing(hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+}
+// raises the dynamic-LDS limit of `fn` once per device; inst: the instantiation's slot in DevState::attr
+int ensure_attr(const void *fn, int lds, int inst, hipStream_t st) {
+    DevState *d = dev_state();
+    if (!d || inst < 0 || inst >= kMaxInst) return PP_ERR_HIP;
+    if (d->attr[inst]) return PP_OK;
+    if (capturing(st)) return PP_ERR_UNSUPPORTED;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return PP_ERR_HIP;
+    d->attr[inst] = true;
+    return PP_OK;
+}
+
 // geometry of the halo kernel for an image size, or false when the shape is not taken (the implicit-GEMM kernel runs it)
-void *g_zero_page = nullptr;
 
 bool halo_geometry(const ConvParams &p, HaloParams &g) {
     if (p.R != 3 || p.pad != 1 || p.dil != 1 || p.C % 32 || p.K % 64) return false;   // K = 64 mod 128: the last channel tile is half empty
@@ -719,25 +752,23 @@ bool halo_geometry(const ConvParams &p, HaloParams &g) {
 template <int MASK, int LGTW>
 int launch_halo_inst(const ConvParams &p, const HaloParams &g, hipStream_t st) {
     const int lds = 2 * 56 * SUB + 6 * (128 * 32 * 2);   // two halo buffers of 56 pieces, weight ring of 6 slices
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_halo<128, MASK, LGTW>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                lds) != hipSuccess)
-            return PP_ERR_HIP;
-        attr_done = true;
-    }
+    static const int inst = g_inst_count.fetch_add(1);
+    if (const int rc = ensure_attr(reinterpret_cast<const void *>(&k_conv3x3_halo<128, MASK, LGTW>), lds, inst, st)) return rc;
     const unsigned ptiles = (unsigned)(p.N * g.tiles);
     const unsigned ids = ((ptiles + 7) / 8) * 8 * (unsigned)((p.K + 127) / 128);   // 8 XCD ranges x ceil(ptiles / 8) x channel tiles
-    static int ncu = 0;      // persistent grid: one workgroup per CU (160 KiB of LDS each), a multiple of 8
-    static bool persist = true;
-    if (ncu == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+    DevState *ds = dev_state();   // persistent grid: one workgroup per CU (160 KiB of LDS each), a multiple of 8
+    if (!ds) return PP_ERR_HIP;
+    if (ds->ncu == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
             return PP_ERR_HIP;
-        ncu = ncu >= 8 ? (ncu / 8) * 8 : 8;
-        const char *e = getenv("POSEPAF_CONV_PERSIST");   // diagnostics: 0 = one tile per workgroup
-        persist = !(e && e[0] == '0');
+        ds->ncu = n >= 8 ? (n / 8) * 8 : 8;
     }
+    const int ncu = ds->ncu;
+    static const bool persist = [] {
+        const char *e = getenv("POSEPAF_CONV_PERSIST");   // diagnostics: 0 = one tile per workgroup
+        return !(e && e[0] == '0');
+    }();
     const dim3 grid(persist && ids > (unsigned)ncu ? (unsigned)ncu : ids);
     ConvParams q = p;
     if (q.stagger < 0) {   // default: spread the starts over half a tile's time (np phases of ~1500 cycles), less when a workgroup has few tiles
@@ -765,6 +796,7 @@ int launch_halo(const ConvParams &p, const HaloParams &g, hipStream_t st) {
     // fragment reads" (6, 7): a hand-placed ds_read whose result nothing consumes may land in a register the compiler has re-used.
     switch (p.dbg) {
         case 0: return launch_halo_mask<0>(p, g, st);
+#ifdef PP_CONV_DIAG
         case 1: return launch_halo_mask<1>(p, g, st);     // no DMA inside the loop
         case 4: return launch_halo_mask<4>(p, g, st);     // no fragment reads
         case 6: return launch_halo_mask<6>(p, g, st);     // DMA + barriers only
@@ -777,6 +809,7 @@ int launch_halo(const ConvParams &p, const HaloParams &g, hipStream_t st) {
         case 1024: return launch_halo_mask<1024>(p, g, st);   // in-kernel clock stamps (pp_conv_debug_clock)
         case 1028: return launch_halo_mask<1028>(p, g, st);
         case 1029: return launch_halo_mask<1029>(p, g, st);
+#endif
         default: return PP_ERR_BAD_ARG;
     }
 }
@@ -784,15 +817,121 @@ int launch_halo(const ConvParams &p, const HaloParams &g, hipStream_t st) {
 template <int BN>
 int launch(const ConvParams &p, hipStream_t st) {
     constexpr int lds = 4 * (BM * 32 * 2 + BN * 32 * 2);  // four phase buffers
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_igemm<BN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
-            hipSuccess)
-            return PP_ERR_HIP;
-        attr_done = true;
-    }
+    static const int inst = g_inst_count.fetch_add(1);
+    if (const int rc = ensure_attr(reinterpret_cast<const void *>(&k_conv_igemm<BN>), lds, inst, st)) return rc;
     const dim3 grid((unsigned)((p.M + BM - 1) / BM), (unsigned)(p.K / BN));
     hipLaunchKernelGGL(k_conv_igemm<BN>, grid, dim3(NTHREADS), lds, st, p);
+    return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
+}
+
+
+// ------------------------------------------------------------------------------------------------ the stem: 7x7, stride 2
+// models/layers_transposed.py:78-87 (Backbone.conv1 + bn1 + LeakyReLU): Conv2d(3, 64, 7, stride 2, padding 3) on the NHWC
+// image.  MIOpen ran it as an implicit GEMM plus a separate bias / activation pass plus a layout copy (4.0 ms of a 176 ms
+// step); its arithmetic is tiny (0.6 % of the forward), its output (2 B x 256 x 256 x 64 fp16 = 2.1 GB at 128 images) is what
+// costs: it is HBM-bound, so this kernel is one pass -- read the image once, write the activation once.
+// GEMM view: an output pixel's K = 7 rows x 8 input pixels x 3 channels = 168 (-> 192).  The window is taken EIGHT pixels wide
+// (2 ox - 4 .. 2 ox + 3; the added left column has zero weights): 24 halves per row = three 16-byte groups, each a CONTIGUOUS
+// run of the NHWC input row that starts on a 4-byte boundary -- the MFMA's pixel fragment (16 pixels x 4 groups of 8 k) is
+// read straight from a linear LDS copy of the input rows, no im2col buffer.  Workgroup = 4 output rows x 64 columns, wave w
+// takes row w: 64 pixels x 64 channels (4 x 4 tiles of v_mfma_f32_16x16x32_f16, weights as A / pixels as B as everywhere in
+// this file), 6 k-steps.  LDS: 24 KB weights (sub-tiles of 16 channels x 32 k, swizzled like k_conv_igemm's) + 13 input rows.
+constexpr int STEM_TW = 64, STEM_TH = 4, STEM_ROWS = 2 * STEM_TH + 5, STEM_K = 192;
+constexpr int STEM_ROWB = ((2 * STEM_TW + 7) * 6 + 15) / 16 * 16 + 16;   // bytes of one staged input row (135 pixels, padded)
+
+struct StemParams {
+    const _Float16 *x, *w, *bias;   // x: (N, H, W, 3); w: (64, 192) k = (row, 8-pixel window, channel), prepared by the host
+    _Float16 *y;                    // (N, H/2, W/2, 64)
+    int N, H, W, Ho, Wo, tiles_x, tiles_y, tiles;
+    float slope;
+};
+
+__global__ __launch_bounds__(256) void k_stem7x7(const StemParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char *s_w = smem;                         // [4 channel tiles][6 k-steps][1 KiB]
+    unsigned char *s_x = smem + 4 * 6 * SUB;           // [13][STEM_ROWB]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // ---- weights -> LDS once per workgroup: sub-tile (ct, t) holds rows 16 ct .. + 15, k 32 t .. + 31, 64 B per row, swizzled
+    for (int i = threadIdx.x; i < 64 * (STEM_K / 8); i += 256) {   // one 16-byte group per step
+        const int n = i / (STEM_K / 8), q = i - n * (STEM_K / 8);
+        const int t = q >> 2, g = q & 3, r16 = n & 15, ct = n >> 4;
+        const half8_t v = *reinterpret_cast<const half8_t *>(p.w + (long)n * STEM_K + q * 8);
+        *reinterpret_cast<half8_t *>(s_w + (ct * 6 + t) * SUB + r16 * 64 + ((g * 16) ^ ((r16 >> 3) << 5))) = v;
+    }
+    const int wfrag = (lane & 15) * 64 + (((lane >> 4) * 16) ^ (((lane & 15) >> 3) << 5));
+    const int g = lane >> 4, pl = lane & 15;
+    for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
+        const int n = tile / (p.tiles_x * p.tiles_y), rem = tile - n * (p.tiles_x * p.tiles_y);
+        const int oy0 = (rem / p.tiles_x) * STEM_TH, ox0 = (rem % p.tiles_x) * STEM_TW;
+        __syncthreads();   // the previous tile's fragment reads are done (and, first time, the weights are in place)
+        // ---- input rows 2 oy0 - 3 .. 2 oy0 + 9, pixels 2 ox0 - 4 .. 2 ox0 + 130, as 8-byte units; outside the image: zeros
+        const long row_bytes = (long)p.W * 6;
+        const long first = (long)(2 * ox0 - 4) * 6;   // byte offset inside an input row; a multiple of 8 (ox0 is even)
+        constexpr int UNITS = (2 * STEM_TW + 7) * 6 / 8 + 1;   // 102 units cover the 135 pixels
+        for (int i = threadIdx.x; i < STEM_ROWS * UNITS; i += 256) {
+            const int r = i / UNITS, u = i - r * UNITS;
+            const int iy = 2 * oy0 - 3 + r;
+            const long b = first + 8L * u;
+            uint2 v = make_uint2(0u, 0u);
+            if ((unsigned)iy < (unsigned)p.H && b >= 0 && b + 8 <= row_bytes)
+                v = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(p.x) + ((long)n * p.H + iy) * row_bytes + b);
+            *reinterpret_cast<uint2 *>(s_x + r * STEM_ROWB + 8 * u) = v;
+        }
+        __syncthreads();
+        float4_t acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 6; t++) {
+            const int q = 4 * t + g;                       // this lane's 8-k group: input row q / 3, 16-byte group q % 3
+            const int r = q < 21 ? q / 3 : 6, jg = q < 21 ? q % 3 : 0;   // groups 21..23 are padding (zero weights): read anything
+            half8_t wf[4], xf[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) wf[j] = *reinterpret_cast<const half8_t *>(s_w + (j * 6 + t) * SUB + wfrag);
+            const unsigned char *rowp = s_x + (2 * wave + r) * STEM_ROWB + 16 * jg;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const unsigned *src = reinterpret_cast<const unsigned *>(rowp + 12 * (16 * i + pl));   // 4-byte aligned
+                union {
+                    unsigned u[4];
+                    half8_t h;
+                } cv;
+                cv.u[0] = src[0], cv.u[1] = src[1], cv.u[2] = src[2], cv.u[3] = src[3];
+                xf[i] = cv.h;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+        }
+        // ---- epilogue from registers: bias + LeakyReLU, 16-byte stores (epilogue_store)
+        ConvParams e;
+        e.bias = p.bias, e.extra = nullptr, e.extra2 = nullptr, e.y = p.y, e.y2 = nullptr;
+        e.K = 64, e.mode = 0, e.slope = p.slope;
+        const int oy = oy0 + wave;
+        epilogue_store<4, 4>(acc, e, lane, 0, [&](int i) -> long {
+            const int ox = ox0 + 16 * i + pl;
+            return (oy < p.Ho && ox < p.Wo) ? ((long)n * p.Ho + oy) * p.Wo + ox : -1;
+        }, true);
+    }
+}
+
+int launch_stem(const StemParams &p, hipStream_t st) {
+    const int lds = 4 * 6 * SUB + STEM_ROWS * STEM_ROWB;
+    static const int inst = g_inst_count.fetch_add(1);
+    if (const int rc = ensure_attr(reinterpret_cast<const void *>(&k_stem7x7), lds, inst, st)) return rc;
+    DevState *ds = dev_state();
+    if (!ds) return PP_ERR_HIP;
+    if (ds->ncu == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            return PP_ERR_HIP;
+        ds->ncu = n >= 8 ? (n / 8) * 8 : 8;
+    }
+    const int grid = p.tiles < ds->ncu * 4 ? p.tiles : ds->ncu * 4;   // four workgroups per CU (36 KB of LDS each), each walks its tiles
+    hipLaunchKernelGGL(k_stem7x7, dim3(grid), dim3(256), lds, st, p);
     return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
 }
 
@@ -800,7 +939,31 @@ int launch(const ConvParams &p, hipStream_t st) {
 
 extern "C" {
 
-// 1 when pp_conv_own_f16 takes the shape: stride 1, square kernel, C_in % 64 == 0, C_out % 64 == 0
+// The stem of the IMHN (models/layers_transposed.py:78-87): y = leaky(conv7x7_stride2_pad3(x, w) + bias) on the NHWC image.
+// x: DEVICE (n, h, w, 3) fp16 with h, w even and w % 4 == 0; w_prepared: DEVICE (64, 192) fp16 in the kernel's k order -- row r
+// (7), window pixel s' (8; s' = 0 is a zero column, s' = s + 1), channel c (3), then zeros up to 192 -- i.e.
+// w_prepared[k][(r * 8 + s') * 3 + c] = weight[k][c][r][s' - 1]; bias fp16[64]; y: DEVICE (n, h / 2, w / 2, 64).
+PP_API int pp_stem7x7_f16(const void *x, const void *w_prepared, const void *bias, void *y, int n, int h, int wd, float slope, void *stream) {
+    if (!x || !w_prepared || !bias || !y || n <= 0 || h <= 0 || wd <= 0) return PP_ERR_BAD_ARG;
+    if ((h & 1) || (wd & 3) || !(slope >= 0.f && slope <= 1.f)) return PP_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_prepared) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(y)) & 15)
+        return PP_ERR_BAD_ARG;
+    StemParams p;
+    p.x = static_cast<const _Float16 *>(x);
+    p.w = static_cast<const _Float16 *>(w_prepared);
+    p.bias = static_cast<const _Float16 *>(bias);
+    p.y = static_cast<_Float16 *>(y);
+    p.N = n, p.H = h, p.W = wd, p.Ho = h / 2, p.Wo = wd / 2;
+    p.tiles_x = (p.Wo + STEM_TW - 1) / STEM_TW;
+    p.tiles_y = (p.Ho + STEM_TH - 1) / STEM_TH;
+    const long tiles = (long)n * p.tiles_x * p.tiles_y;
+    if (tiles >= (1L << 31)) return PP_ERR_TOO_LARGE;
+    p.tiles = (int)tiles;
+    p.slope = slope;
+    return launch_stem(p, static_cast<hipStream_t>(stream));
+}
+
+// 1 when pp_conv_own_f16 takes the shape: stride 1, square kernel, C_in % 32 == 0, C_out % 64 == 0
 // Diagnostics (POSEPAF_CONV_DBG with bit 1024): median over workgroups of the shader-clock cycles a workgroup spent per section,
 // summed over its tiles, in the last stamped launch.  out[0..4] = wait for first DMA + stores / first fragment reads / main loop /
 // next tile's decode + DMA issue / epilogue; out[5] = main loop in 100 MHz ticks (clock in GHz = out[2] / out[5] / 10).
@@ -842,8 +1005,12 @@ PP_API int pp_conv_own_ex_f16(const void *x, const void *w, const void *bias, co
     const int ho = h + 2 * pad - dilation * (ksize - 1), wo = wd + 2 * pad - dilation * (ksize - 1);
     if (ho <= 0 || wo <= 0) return PP_ERR_BAD_ARG;
     if (bn != 0 && bn != 512 && ((bn != 256 && bn != 128 && bn != 64) || c_out % bn)) return PP_ERR_UNSUPPORTED;
-    if (!g_zero_page) {
-        if (hipMalloc(&g_zero_page, 256) != hipSuccess || hipMemset(g_zero_page, 0, 256) != hipSuccess) return PP_ERR_HIP;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    DevState *ds = dev_state();
+    if (!ds) return PP_ERR_HIP;
+    if (!ds->zero) {
+        if (capturing(st)) return PP_ERR_UNSUPPORTED;   // first use on this device allocates: not inside a capture
+        if (hipMalloc(&ds->zero, 256) != hipSuccess || hipMemset(ds->zero, 0, 256) != hipSuccess) return PP_ERR_HIP;
     }
     ConvParams p;
     p.x = static_cast<const _Float16 *>(x);
@@ -854,16 +1021,19 @@ PP_API int pp_conv_own_ex_f16(const void *x, const void *w, const void *bias, co
     p.up = upsampled_input;
     p.y = static_cast<_Float16 *>(y);
     p.y2 = static_cast<_Float16 *>(y2);
-    p.zero = g_zero_page;
+    p.zero = ds->zero;
     p.N = n; p.H = h; p.W = wd; p.C = c_in; p.K = c_out; p.R = ksize; p.pad = pad; p.dil = dilation; p.Ho = ho; p.Wo = wo;
     p.M = (long)n * ho * wo;
     p.mode = extra_mode;
     p.slope = slope;
+#ifdef PP_CONV_DIAG   // the diagnostics library only (make diag): compile-time ablated instances behind POSEPAF_CONV_DBG
     static const int dbg = std::getenv("POSEPAF_CONV_DBG") ? std::atoi(std::getenv("POSEPAF_CONV_DBG")) : 0;
     p.dbg = dbg;
+#else
+    p.dbg = 0;            // the product library has no ablated instance and reads no such variable
+#endif
     static const int stagger = std::getenv("POSEPAF_CONV_STAGGER") ? std::atoi(std::getenv("POSEPAF_CONV_STAGGER")) : -1;   // -1: launcher's default
     p.stagger = stagger;
-    hipStream_t st = static_cast<hipStream_t>(stream);
     if (bn == 0 || bn == 512) {   // 512: the halo-tile 3x3 kernel
         HaloParams g;
         if (halo_geometry(p, g)) return launch_halo(p, g, st);

@@ -1,17 +1,20 @@
 // posepaf_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for the bottom-up pose post-processing
-// path.  Three launches per batch of images, every input byte read from HBM exactly once:
+// path.  TWO launches per batch of images, every input byte read from HBM exactly once:
 //
 //   K_A  k_heat_peaks    grid (18, B)  one 256-thread workgroup per keypoint channel
 //        flip-average the channel straight into LDS (A2), plus-shaped NMS with row-major ordered compaction
-//        by wave ballots (A3), x4 bicubic patch refinement + wave arg-max per peak (A4)
-//   K_B  k_limb_connect  grid (30, B)  one workgroup per limb channel
-//        flip-average the limb map into LDS (A2), line-integral scoring of every (a,b) peak pair with the
-//        x4 bicubic evaluated on the fly at the sampled pixel instead of materialising the 31.5 MB
-//        up-sampled map (A4'+A5), ordered compaction of accepted candidates, the reference's sort order
-//        and greedy matching (A6)
-//   K_C  k_assemble      grid (B)      one wave per image
-//        greedy person assembly with the reference's exact (bug-compatible) update rules (A7), pruning,
-//        fixed-size result records
+//        by wave ballots (A3), x4 bicubic patch refinement + wave arg-max per peak (A4); its last workgroup
+//        ranks the images by matching load (dispatch order of K_B)
+//   K_B  k_limb_connect  grid (31, B)  workgroups 0..29 of an image: one limb channel each
+//        flip-average the limb map into LDS rows padded by 16 bytes (A2), line-integral scoring of every (a,b)
+//        peak pair with the x4 bicubic evaluated on the fly at the sampled pixel instead of materialising the
+//        31.5 MB up-sampled map (A4'+A5; sparse limbs spread the SAMPLES of a pair over lanes), ordered
+//        compaction of accepted candidates, the reference's sort order and greedy matching (A6), publication
+//        of the limb through a per-limb flag;
+//        workgroup 30 of an image: ONE wave that assembles the image (A7) WHILE its limbs are matched -- it
+//        consumes limb 0, 1, ... as each is published, prunes, and writes the fixed-size result record
+//   (k_assemble_wave / k_assemble: the assembly as its own launch -- diagnostics, the drop-in process_paf and the
+//   Python-twin path; k_accumulate_scales + k_fullres_peaks + ...: the original path at image resolution.)
 //
 // No MFMA anywhere: this is gather/compare/reduce work bounded by HBM.
 // Floating point: every expression mirrors the reference's operation ORDER and rounding (x86-64 g++ without

@@ -2,7 +2,11 @@
 (NHWC is also the layout the images arrive in, utils/parse_skeletons.py:60-73, so the input permute is free),
 dead heads removed, whole forward replayed from a HIP graph.
 
-The convolutions run on PyTorch-ROCm (MIOpen); what this module adds is structural:
+Every stride-1 convolution with channel counts that are multiples of 8 runs as ONE fused kernel of libposepaf.so -- the
+hand-written LDS-DMA + MFMA kernels of csrc/posepaf_conv_own.hip (3x3 halo-tile kernel incl. the hourglass' upsample and adds,
+implicit-GEMM kernel) or a composable_kernel template with this library's epilogue (csrc/posepaf_conv_inst.hip), whichever the
+per-shape timing picks; the choice table can be saved, loaded, hashed and broadcast (save_table / load_table / table_hash).
+Only the 7x7 stride-2 stem and the 50-channel heads stay on PyTorch-ROCm (MIOpen / hipBLASLt).  Structural changes:
   * BN (eval) folded:  w' = w * g / sqrt(var + eps),  b' = beta - mean * g / sqrt(var + eps)
   * only `[-1][0]` (last stage, full-resolution scale) is produced -- the sole output the inference path reads
     (utils/parse_skeletons.py:80); the last stage's coarse-scale feature/pred heads feed nothing and are skipped
@@ -146,6 +150,24 @@ def _stream(t):
     return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
+_fallback_seen = set()
+
+
+def _fallback(name: str, x: torch.Tensor, why: str) -> None:
+    """A DEVICE tensor that a HIP helper does not take runs on the torch operator instead: say so once per (helper, reason)
+    (POSEPAF_STRICT=1: raise).  Host tensors (CPU unit tests of the module structure) are the torch path by design."""
+    if not x.is_cuda:
+        return
+    msg = f"posepaf.fused_model.{name}: torch fallback on a device tensor ({why}; dtype {x.dtype}, shape {tuple(x.shape)})"
+    if os.environ.get("POSEPAF_STRICT", "0") == "1":
+        raise RuntimeError(msg)
+    key = (name, why)
+    if key not in _fallback_seen:
+        _fallback_seen.add(key)
+        import warnings
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+
+
 def hip_bias_act_(y: torch.Tensor, bias: torch.Tensor, res, act: bool, post=None) -> torch.Tensor:
     """In place y = act(y + bias[c] (+ res)) (+ post) by the fused HIP epilogue kernel (csrc/posepaf_epilogue.hip)."""
     from . import _lib
@@ -162,6 +184,7 @@ def maxpool2(x: torch.Tensor) -> torch.Tensor:
     """2x2/2 max pool; HIP kernel on channels-last fp16, torch elsewhere."""
     n, c, h, w = x.shape
     if not (x.is_cuda and x.dtype == torch.float16 and c % 8 == 0 and h % 2 == 0 and w % 2 == 0):
+        _fallback("maxpool2", x, "needs fp16, channels % 8 == 0, even height and width")
         return F.max_pool2d(x, 2, 2)
     from . import _lib
     x = _cl(x)
@@ -174,6 +197,7 @@ def upsample2(x: torch.Tensor) -> torch.Tensor:
     """nearest x2 upsample; HIP kernel on channels-last fp16, torch elsewhere."""
     n, c, h, w = x.shape
     if not (x.is_cuda and x.dtype == torch.float16 and c % 8 == 0):
+        _fallback("upsample2", x, "needs fp16 and channels % 8 == 0")
         return F.interpolate(x, scale_factor=2, mode="nearest")
     from . import _lib
     x = _cl(x)
@@ -186,6 +210,7 @@ def add3(a: torch.Tensor, b: torch.Tensor, c=None) -> torch.Tensor:
     """a + b (+ c) in one pass; HIP kernel on channels-last fp16, torch elsewhere."""
     if not (a.is_cuda and a.dtype == torch.float16 and a.numel() % 8 == 0 and a.shape == b.shape
             and (c is None or c.shape == a.shape)):
+        _fallback("add3", a, "needs fp16 tensors of one shape with a multiple of 8 elements")
         return a + b if c is None else a + b + c
     from . import _lib
     a, b = _cl(a), _cl(b)
@@ -199,6 +224,7 @@ def channel_mean(x: torch.Tensor) -> torch.Tensor:
     """(n, c, h, w) -> (n, c) mean over the pixels (the SE squeeze); HIP kernel on channels-last fp16, torch elsewhere."""
     n, c, h, w = x.shape
     if not (x.is_cuda and x.dtype == torch.float16 and c % 8 == 0 and c <= 2048):
+        _fallback("channel_mean", x, "needs fp16 and channels % 8 == 0, <= 2048")
         return x.mean(dim=(2, 3))
     from . import _lib
     x = _cl(x)
@@ -213,6 +239,7 @@ def channel_scale(x: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
     """x * s[:, :, None, None] (the SE excitation); HIP kernel on channels-last fp16, torch elsewhere."""
     n, c, h, w = x.shape
     if not (x.is_cuda and x.dtype == torch.float16 and s.dtype == torch.float16 and c % 8 == 0):
+        _fallback("channel_scale", x, "needs fp16 and channels % 8 == 0")
         return x * s[:, :, None, None]
     from . import _lib
     x = _cl(x)
@@ -486,6 +513,34 @@ class FConv(nn.Module):
         return y + post if post is not None else y
 
 
+class FStem(FConv):
+    """The 7x7 / stride 2 stem (models/layers_transposed.py:78-87) on the one-pass HIP kernel pp_stem7x7_f16; the weights are
+    re-laid once into the kernel's k order (7 rows x 8-pixel window x 3 channels, zero column on the left, padded to 192)."""
+
+    def __init__(self, conv, bn, act):
+        super().__init__(conv, bn, act)
+        w = self.weight.detach()                                   # (64, 3, 7, 7), BN folded
+        wp = torch.zeros((w.shape[0], 7, 8, 3), dtype=w.dtype)
+        wp[:, :, 1:, :] = w.permute(0, 2, 3, 1)                    # [k][r][s + 1][c]
+        prepared = torch.zeros((w.shape[0], 192), dtype=w.dtype)
+        prepared[:, :168] = wp.reshape(w.shape[0], 168)
+        self.prepared = nn.Parameter(prepared, requires_grad=False)
+
+    def forward(self, x, res=None, post=None):
+        n, c, h, w = x.shape
+        ok = (x.is_cuda and x.dtype == torch.float16 and res is None and post is None and c == 3 and self.weight.shape[0] == 64
+              and tuple(self.weight.shape[2:]) == (7, 7) and self.stride == (2, 2) and self.padding == (3, 3) and h % 2 == 0
+              and w % 4 == 0 and x.permute(0, 2, 3, 1).is_contiguous())
+        if not ok:
+            _fallback("stem", x, "needs an fp16 NHWC image with even height and width % 4 == 0")
+            return super().forward(x, res, post)
+        from . import _lib
+        y = torch.empty((n, 64, h // 2, w // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        _lib.check(_lib.load().pp_stem7x7_f16(_ptr(x), _ptr(self.prepared), _ptr(self.bias), _ptr(y), n, h, w,
+                                              LEAK if self.act else 1.0, _stream(x)))
+        return y
+
+
 def _fconv_from_block(m, act=None):  # models.layers_transposed.Conv / DilatedConv
     return FConv(m.conv, m.bn, m.relu is not None if act is None else act)
 
@@ -562,7 +617,7 @@ class FusedIMHN(nn.Module):
         p = net.posenet
         self.S, self.K = p.num_stages, p.num_scales
         pre = p.pre
-        self.stem = FConv(pre.conv1, pre.bn1, True)
+        self.stem = FStem(pre.conv1, pre.bn1, True)
         self.res1, self.res2 = FResidual(pre.res1), FResidual(pre.res2)
         self.dil = nn.ModuleList([_fconv_from_block(d) for d in pre.dilation])
         self.hg = nn.ModuleList([FHourglass(h) for h in p.hourglass])
@@ -579,7 +634,9 @@ class FusedIMHN(nn.Module):
     def from_network(cls, net):
         return cls(net)
 
-    def forward(self, imgs):
+    def forward(self, imgs, stage_preds: bool = False):
+        """stage_preds=True (tests): -> the scale-0 prediction of EVERY stage, i.e. the reference's out[t][0] for t = 0..S-1."""
+        seen = []
         x = imgs.permute(0, 3, 1, 2)  # NHWC storage viewed as NCHW == channels_last: no copy
         x = self.stem(x)
         x = self.res2(maxpool2(self.res1(x)))
@@ -596,8 +653,9 @@ class FusedIMHN(nn.Module):
                 hg = [hg[0]] + [hg[s] + caches[s] for s in scales if s > 0]
             feats = [self.feat[t][s](hg[s]) for s in scales]
             preds = [self.head[t][s](feats[s]) for s in scales]
+            seen.append(preds[0])
             if last:
-                return preds[0]
+                return seen if stage_preds else preds[0]
             # cache_s = merge_feat(feat_s) + merge_pred(pred_s); x + cache_0 leaves the scale-0 convolution as a second output
             c0, x = self.mfeat[t][0].forward_dual(feats[0], self.mpred[t][0].conv_only(preds[0]), x)
             caches = [c0] + [self.mfeat[t][s](feats[s], self.mpred[t][s].conv_only(preds[s])) for s in scales if s > 0]

@@ -1,6 +1,10 @@
 """End-to-end inference pipeline on one GPU: uint8 images resident in HBM -> person records.
 
-    pre-process (A0)  ->  IMHN forward (A1, PyTorch-ROCm convolutions)  ->  K_A / K_B / K_C (A2..A7, HIP)
+    pre-process (A0)  ->  IMHN forward (A1: fused convolution kernels of libposepaf.so, posepaf/fused_model.py)
+                      ->  K_A (peaks) / K_B (limb matching + the person assembly streaming under it) (A2..A7, HIP)
+
+The batched engine both bench.py and evaluate.py run on is posepaf/engine.py; this module keeps the simple, eager,
+one-call-per-batch form (tests, demo_image.py, the original path).
 
 Replaces the per-image serial loop of evaluate.py:262-267 + process() :70-129 by batched device work: the
 network output never leaves HBM (the reference copies it to the host at utils/parse_skeletons.py:80).

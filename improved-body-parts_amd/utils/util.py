@@ -24,6 +24,8 @@ def keypoint_heatmap_nms(heat, kernel=3, thre=0.1):
         out = _hip_keypoint_nms(heat, float(thre))
         if out is not None:
             return out
+        _warn_once("keypoint_heatmap_nms: the HIP peak kernel did not take this map (too large for its LDS tile, or a channel "
+                   "with more than 128 peaks) -- the torch max-pool expression runs instead")
     pad = (kernel - 1) // 2
     hmax = F.max_pool2d(F.pad(heat, (pad, pad, pad, pad), mode="reflect"), (kernel, kernel), stride=1, padding=0)
     keep = (hmax == heat).float() * (heat >= thre).float()
@@ -45,6 +47,18 @@ def refine_centroid(scorefmp, anchor, radius):
 
 
 _nms_ctx = {}
+_warned = set()
+
+
+def _warn_once(msg):
+    """a device tensor that leaves the HIP path says so once (POSEPAF_STRICT=1: raises instead)"""
+    import os
+    import warnings
+    if os.environ.get("POSEPAF_STRICT", "0") == "1":
+        raise RuntimeError(msg)
+    if msg not in _warned:
+        _warned.add(msg)
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
 
 
 def _hip_keypoint_nms(heat, thre):

@@ -187,10 +187,11 @@ PP_API int pp_conv_f16(const void *x, const void *w, const void *bias, const voi
 
 /* A1 forward: the same fused convolution as pp_conv_f16 -- identical arguments and semantics -- as a HAND-WRITTEN implicit-GEMM
  * kernel (csrc/posepaf_conv_own.hip: 256-pixel x bn-channel workgroup tiles, LDS-DMA staging, v_mfma_f32_16x16x32_f16, epilogue
- * from registers; no composable_kernel).  Needs c_in % 64 == 0 and c_out % 64 == 0 (pp_conv_own_supported).  bn = output
+ * from registers; no composable_kernel).  Needs c_in % 32 == 0 and c_out % 64 == 0 (pp_conv_own_supported).  bn = output
  * channels per workgroup: 256, 128 or 64 (must divide c_out), 0 = the largest that divides c_out. */
 PP_API int pp_conv_own_supported(int c_in, int c_out, int ksize);
-/* Diagnostics: after a launch of the 3x3 halo kernel with POSEPAF_CONV_DBG bit 1024 set, the median over the first nwg
+/* Diagnostics (the diagnostics build only, `make -C csrc diag`: the product library compiles no ablated instance and ignores
+ * POSEPAF_CONV_DBG): after a launch of the 3x3 halo kernel with POSEPAF_CONV_DBG bit 1024 set, the median over the first nwg
  * workgroups of the shader-clock cycles spent per section (summed over the workgroup's tiles): out6[0..4] = wait for the
  * first DMA and the previous stores / first fragment reads / main loop / next tile's decode + DMA issue / epilogue;
  * out6[5] = the main loop in 100 MHz ticks.  No reference counterpart. */
@@ -210,6 +211,13 @@ PP_API int pp_conv_own_f16(const void *x, const void *w, const void *bias, const
 PP_API int pp_conv_own_ex_f16(const void *x, const void *w, const void *bias, const void *extra, const void *extra2, void *y, void *y2,
                               int n, int h, int wd, int c_in, int c_out, int ksize, int pad, int dilation, int extra_mode, float slope,
                               int bn, int upsampled_input, void *stream);
+
+/* A1, the stem (models/layers_transposed.py:78-87 Backbone.conv1 + bn1 + LeakyReLU): y = leaky(conv(x, w, 7x7, stride 2, padding 3)
+ * + bias) in one HBM-bound pass.  x: DEVICE (n, h, w, 3) NHWC fp16, h even, w % 4 == 0; w_prepared: DEVICE (64, 192) fp16,
+ * w_prepared[k][(r * 8 + s1) * 3 + c] = weight[k][c][r][s1 - 1] (zeros for s1 = 0 and past 168); bias fp16[64];
+ * y: DEVICE (n, h / 2, w / 2, 64) NHWC fp16. */
+PP_API int pp_stem7x7_f16(const void *x, const void *w_prepared, const void *bias, void *y, int n, int h, int w, float slope,
+                          void *stream);
 
 /* A0 pre-processing (utils/parse_skeletons.py:52-73, utils/util.py:44-65) of a batch of equally sized BGR uint8 DEVICE
  * images (batch, h, w, 3): pad bottom/right to a multiple of pad_to with pad_value, divide by 255, and write each image
