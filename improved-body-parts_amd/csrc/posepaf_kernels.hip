@@ -1387,6 +1387,18 @@ __device__ __forceinline__ void assemble_pass(AsmState &S, const AsmWaveLds &A, 
     SkelCache K[NB];
 #pragma unroll
     for (int b = 0; b < NB; b++) load_cache(K[b], A, b * 64 + lane, part1, part2, b * 64 + lane < S.nb);
+    // One or two connections (the common case of a sparse image: thirty limbs of a person or two): the classification below
+    // costs more than the reference's scan itself -- every connection goes through the scan (step 3), which IS the reference's
+    // rule for any connection, so the result is the same by construction.
+    const bool few = mc <= 2;
+    int myk[NB];
+    bool isnew = false;
+    unsigned long long confm = few ? (1ull << mc) - 1ull : 0ull;
+    int f_id2[NB];
+    float f_cs[NB], f_cl[NB], f_ps2[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) myk[b] = -1, f_id2[b] = 0, f_cs[b] = f_cl[b] = f_ps2[b] = 0.0f;
+    if (!few) {
     if (have) {
         A.cb1[id1 - off1] = tag | lane;  // end points are pairwise different within a limb: no write conflicts
         A.cb2[id2 - off2] = tag | lane;
@@ -1394,7 +1406,6 @@ __device__ __forceinline__ void assemble_pass(AsmState &S, const AsmWaveLds &A, 
     A.cnt[lane] = 0;
     wave_lds_sync();
     // ---- 2. classification: cnt[c] = number of skeletons matching connection c (:143-150), + 256 when c shares one
-    int myk[NB];
 #pragma unroll
     for (int b = 0; b < NB; b++) {
         const int r1 = K[b].p1 - off1, r2 = K[b].p2 - off2;  // erased / unused slots: negative
@@ -1415,11 +1426,9 @@ __device__ __forceinline__ void assemble_pass(AsmState &S, const AsmWaveLds &A, 
     wave_lds_sync();
     const int cw = have ? A.cnt[lane] : 0;
     const bool conflict = cw >= 2;  // two or more skeletons (possible merge / no action), or a shared skeleton
-    const bool isnew = have && cw == 0;
-    unsigned long long confm = __ballot(conflict);
+    isnew = have && cw == 0;
+    confm = __ballot(conflict);
     // connection words for the skeleton lanes that apply a found-1 update in a run
-    int f_id2[NB];
-    float f_cs[NB], f_cl[NB], f_ps2[NB];
     bool any_par = false;
 #pragma unroll
     for (int b = 0; b < NB; b++) {
@@ -1436,6 +1445,7 @@ __device__ __forceinline__ void assemble_pass(AsmState &S, const AsmWaveLds &A, 
             f_ps2[b] = __shfl(ps2, src);
         }
     }
+    }   // !few
     if (stamps) S.class_cycles += (long long)clock64() - tc0;
     // ---- 3. in connection order: maximal runs of independent connections in one step, the others one by one
     // (a run's found-1 updates cannot be hoisted in front of an earlier flagged connection: its merge may ADD two ids into an

@@ -3,7 +3,7 @@
 profiles/r02_pmc_traffic.json: HBM bytes per launch of K_A (k_heat_peaks) and K_B (k_limb_connect, which includes the person
 assembly since round 2).
 
-    python tools/pmc_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <B>
+    python tools/pmc_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <B> [output name, default r03_pmc_traffic.json]
 
 rocprofv3 reports these counters in KiB; on gfx950 FETCH_SIZE counts half of the bytes of wide coalesced streaming reads
 (MI355X_MICROARCH.md, section HBM), so traffic = (2 * FETCH_SIZE + WRITE_SIZE) * 1024."""
@@ -33,7 +33,7 @@ def per_launch(d, counter):
 
 
 fetch, write = per_launch(fdir, "FETCH_SIZE"), per_launch(wdir, "WRITE_SIZE")
-out_path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+out_path = os.path.join(ROOT, "profiles", sys.argv[4] if len(sys.argv) > 4 else "r03_pmc_traffic.json")
 out = json.load(open(out_path)) if os.path.exists(out_path) else {
     "_note": "HBM traffic per launch from rocprofv3 --pmc (separate passes: FETCH_SIZE alone, WRITE_SIZE alone) of `bench.py "
              "--postproc-only --batch B`, merged by tools/pmc_traffic.py. rocprofv3 reports KiB. On gfx950 FETCH_SIZE counts exactly "
