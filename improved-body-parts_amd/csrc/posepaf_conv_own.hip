@@ -42,6 +42,8 @@ struct ConvParams {
     _Float16 *y, *y2;  // y2: second output of mode 4
     const void *zero;  // >= 16 zero bytes: source of every tap that falls outside the image
     int N, H, W, C, K, R, pad, dil, Ho, Wo;
+    int ldy;           // elements between consecutive pixels of y (K: packed; larger: y is a channel slice of a wider tensor,
+                       // e.g. one half of the backbone's concatenation, models/layers_transposed.py:193-195)
     long M;            // N * Ho * Wo
     int mode;          // 0 none, 1 extra added before the activation, 2 after, 3 extra AND extra2 after (3x3 halo kernel),
                        // 4 = mode 1 plus a SECOND OUTPUT y2 = y + extra2 (every kernel)
@@ -128,8 +130,59 @@ __device__ __forceinline__ void epilogue_body(const float4_t (&acc)[PT][CT], con
                         out2[2 * e + 1] = (_Float16)((float)out[2 * e + 1] + (float)ev2[2 * e + 1]);
                     }
                 }
-                if (do_store) *reinterpret_cast<half8_t *>(p.y + o) = out;
+                if (do_store) *reinterpret_cast<half8_t *>(p.y + (m * p.ldy + co)) = out;
                 if (MODE == 4 && do_store) *reinterpret_cast<half8_t *>(p.y2 + o) = out2;
+            }
+        }
+    }
+}
+
+// The same epilogue with the `extra` / `extra2` vectors ALREADY in registers (k_pw requests them before its MFMAs, so their
+// latency hides under the matrix work instead of following it): pre[i][jp / 2] / pre2[...] = the 16 bytes this lane adds to
+// pixel tile i, channel-tile pair jp.  Same arithmetic, same stores as epilogue_body.
+template <int MODE, int PT, int CT, typename PixelOf>
+__device__ __forceinline__ void epilogue_preloaded(const float4_t (&acc)[PT][CT], const ConvParams &p, int lane, int nbase,
+                                                   PixelOf pixel_of, const half8_t (&pre)[PT][CT / 2], const half8_t (&pre2)[PT][CT / 2]) {
+    const int g = lane >> 4, odd = g & 1, cbase = (g & ~1) * 4;
+    const float2_t slope2 = float2_t{p.slope, p.slope};
+#pragma unroll
+    for (int jp = 0; jp < CT; jp += 2) {
+        const int co = nbase + (jp + odd) * 16 + cbase;
+        const half8_t bv = *reinterpret_cast<const half8_t *>(p.bias + co);
+        float2_t b2[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) b2[e] = float2_t{(float)bv[2 * e], (float)bv[2 * e + 1]};
+#pragma unroll
+        for (int i = 0; i < PT; i++) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float a0 = acc[i][jp][e], a1 = acc[i][jp + 1][e];
+                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(a0), __float_as_uint(a1), false, false);
+                v[e] = __builtin_bit_cast(float, (unsigned)sw[0]);
+                v[4 + e] = __builtin_bit_cast(float, (unsigned)sw[1]);
+            }
+            const long m = pixel_of(i);
+            if (m >= 0) {
+                const half8_t ev = pre[i][jp / 2], ev2 = pre2[i][jp / 2];
+                half8_t out, out2;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float2_t t = float2_t{v[2 * e], v[2 * e + 1]} + b2[e];
+                    const float2_t x = float2_t{(float)ev[2 * e], (float)ev[2 * e + 1]};
+                    if (MODE == 1 || MODE == 4) t += x;
+                    const float2_t u = t * slope2;
+                    t = float2_t{fmaxf(t[0], u[0]), fmaxf(t[1], u[1])};
+                    if (MODE == 2) t += x;
+                    out[2 * e] = (_Float16)t[0];
+                    out[2 * e + 1] = (_Float16)t[1];
+                    if (MODE == 4) {
+                        out2[2 * e] = (_Float16)((float)out[2 * e] + (float)ev2[2 * e]);
+                        out2[2 * e + 1] = (_Float16)((float)out[2 * e + 1] + (float)ev2[2 * e + 1]);
+                    }
+                }
+                *reinterpret_cast<half8_t *>(p.y + (m * p.ldy + co)) = out;
+                if (MODE == 4) *reinterpret_cast<half8_t *>(p.y2 + (m * p.K + co)) = out2;
             }
         }
     }
@@ -825,6 +878,135 @@ int launch(const ConvParams &p, hipStream_t st) {
 }
 
 
+// ------------------------------------------------------------------------------------------------ 1x1, streaming
+// The 1x1 convolutions of the IMHN (bottleneck c1 / c3 of models/layers_transposed.py:12-48, the merge convolutions and heads of
+// models/posenet.py:60-118) are HBM-bound: 50 flop per byte against the chip's ~300.  What costs is bytes and passes, so this
+// kernel is a stream with the neighbouring element-wise passes folded in:
+//   y = act(conv1x1(x * scale[n]) + bias (+ extra))   and optionally   y2 = y + extra2
+//   * `scale` (n, K): the SE block's per-sample channel gains (models/layers_transposed.py:289-310) applied to the INPUT fragment
+//     in registers -- binary16 products, i.e. exactly the tensor a separate x * s pass would have written; that pass disappears;
+//   * y2: `x + cache` next to `cache` (models/posenet.py:116-118) from one pass;
+//   * ldy: y may be a channel slice of a wider tensor.
+// Structure: persistent workgroups of 8 waves, the weights of the workgroup's output-channel range resident in LDS (sub-tiles of
+// 16 channels x 32 k, swizzled like k_conv_igemm's), NO barrier after that: every wave walks its own groups of 32 pixels --
+// the pixel fragments of the MFMA come straight from global memory into registers (lane = pixel x 8-k group: 16 bytes, a
+// pixel's k-steps are consecutive 64-byte pieces of its row), all K of the group is held in registers, and the output
+// channels are produced 64 at a time (weights as A, pixels as B: a lane finishes four consecutive channels of a pixel, the
+// shared epilogue stores 16 bytes).  grid.y splits C_out when its weights exceed LDS (the input is then read once per split).
+struct PwParams {
+    const _Float16 *x, *scale, *w;
+    ConvParams e;          // bias, extra, extra2, y, y2, K (= C_out), ldy, mode, slope: the shared epilogue's view
+    long M;                // pixels
+    int Kin, hw, n_per_wg; // input channels, pixels per image (scale index), output channels per workgroup
+};
+
+// PT: 16-pixel tiles per wave and group (2: 32 pixels; 4: 64 pixels for the narrow inputs, whose groups are otherwise too small
+// to pay for a group's fixed cost)
+template <int KT, int PT>
+__global__ __launch_bounds__(512) void k_pw(const PwParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n_base = blockIdx.y * p.n_per_wg;
+    const int Nw = p.e.K - n_base < p.n_per_wg ? p.e.K - n_base : p.n_per_wg;   // a multiple of 64
+    constexpr int KG = KT * 4;   // 16-byte groups per weight row
+    for (int i = threadIdx.x; i < Nw * KG; i += 512) {
+        const int n = i / KG, q = i - n * KG;
+        const int t = q >> 2, g = q & 3, r16 = n & 15, nt = n >> 4;
+        const half8_t v = *reinterpret_cast<const half8_t *>(p.w + (long)(n_base + n) * (KT * 32) + q * 8);
+        *reinterpret_cast<half8_t *>(smem + (nt * KT + t) * SUB + r16 * 64 + ((g * 16) ^ ((r16 >> 3) << 5))) = v;
+    }
+    __syncthreads();
+    const int wfrag = (lane & 15) * 64 + (((lane >> 4) * 16) ^ (((lane & 15) >> 3) << 5));
+    const int g = lane >> 4, pl = lane & 15;
+    constexpr int GP = PT * 16;   // pixels per group
+    const long groups = (p.M + GP - 1) / GP;
+    for (long grp = (long)blockIdx.x * 8 + wave; grp < groups; grp += (long)gridDim.x * 8) {
+        const long m0 = grp * GP;
+        half8_t xf[PT][KT];
+#pragma unroll
+        for (int i = 0; i < PT; i++) {
+            const long m = m0 + 16 * i + pl;
+            const _Float16 *row = p.x + (m < p.M ? m : 0) * (KT * 32) + g * 8;
+#pragma unroll
+            for (int t = 0; t < KT; t++) xf[i][t] = *reinterpret_cast<const half8_t *>(row + t * 32);
+        }
+        if (p.scale) {   // the SE gains of this group's image (a group never straddles two images: hw % 64 == 0 is asked of the caller)
+            const _Float16 *sc = p.scale + (m0 / p.hw) * (KT * 32) + g * 8;
+#pragma unroll
+            for (int t = 0; t < KT; t++) {
+                const half8_t sv = *reinterpret_cast<const half8_t *>(sc + t * 32);
+#pragma unroll
+                for (int i = 0; i < PT; i++) xf[i][t] = xf[i][t] * sv;
+            }
+        }
+        for (int c0 = 0; c0 < Nw; c0 += 64) {
+            float4_t acc[PT][4];
+#pragma unroll
+            for (int i = 0; i < PT; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+            // the tensors the epilogue adds: requested BEFORE the matrix work of this 64-channel slice (16 bytes per lane and
+            // (pixel tile, channel-tile pair): the lane's eight channels after the epilogue's lane exchange)
+            half8_t pre[PT][2], pre2[PT][2];
+            {
+                const int gg = lane >> 4, odd = gg & 1, cbase = (gg & ~1) * 4;
+#pragma unroll
+                for (int i = 0; i < PT; i++) {
+                    const long m = m0 + 16 * i + pl;
+                    const long mm = m < p.M ? m : 0;
+#pragma unroll
+                    for (int jp = 0; jp < 2; jp++) {
+                        const long o = mm * p.e.K + n_base + c0 + (2 * jp + odd) * 16 + cbase;
+                        pre[i][jp] = p.e.mode != 0 ? *reinterpret_cast<const half8_t *>(p.e.extra + o) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+                        pre2[i][jp] = p.e.mode == 4 ? *reinterpret_cast<const half8_t *>(p.e.extra2 + o) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+                    }
+                }
+            }
+            const unsigned char *wb = smem + ((c0 >> 4) * KT) * SUB + wfrag;
+#pragma unroll
+            for (int t = 0; t < KT; t++) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const half8_t wf = *reinterpret_cast<const half8_t *>(wb + (j * KT + t) * SUB);
+#pragma unroll
+                    for (int i = 0; i < PT; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[i][t], acc[i][j], 0, 0, 0);
+                }
+            }
+            auto pix = [&](int i) -> long {
+                const long m = m0 + 16 * i + pl;
+                return m < p.M ? m : -1;
+            };
+            if (p.e.mode == 0) epilogue_preloaded<0, PT, 4>(acc, p.e, lane, n_base + c0, pix, pre, pre2);
+            else if (p.e.mode == 1) epilogue_preloaded<1, PT, 4>(acc, p.e, lane, n_base + c0, pix, pre, pre2);
+            else if (p.e.mode == 2) epilogue_preloaded<2, PT, 4>(acc, p.e, lane, n_base + c0, pix, pre, pre2);
+            else epilogue_preloaded<4, PT, 4>(acc, p.e, lane, n_base + c0, pix, pre, pre2);
+        }
+    }
+}
+
+template <int KT, int PT = (KT <= 2 ? 4 : 2)>
+int launch_pw_inst(const PwParams &p, int n_split, hipStream_t st) {
+    const int lds = p.n_per_wg * KT * 64;   // n_per_wg rows x (KT * 32) halves
+    static const int inst = g_inst_count.fetch_add(1);
+    if (const int rc = ensure_attr(reinterpret_cast<const void *>(&k_pw<KT, PT>), lds, inst, st)) return rc;
+    DevState *ds = dev_state();
+    if (!ds) return PP_ERR_HIP;
+    if (ds->ncu == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            return PP_ERR_HIP;
+        ds->ncu = n >= 8 ? (n / 8) * 8 : 8;
+    }
+    const int per_cu = lds <= 40 * 1024 ? 3 : (lds <= 76 * 1024 ? 2 : 1);   // workgroups that fit a CU's 160 KiB of LDS
+    const long groups = (p.M + PT * 16 - 1) / (PT * 16);
+    long gx = (long)ds->ncu * per_cu / n_split;
+    if (gx < 1) gx = 1;
+    if (gx * 8 > groups) gx = (groups + 7) / 8;
+    hipLaunchKernelGGL((k_pw<KT, PT>), dim3((unsigned)gx, (unsigned)n_split), dim3(512), lds, st, p);
+    return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
+}
+
 // ------------------------------------------------------------------------------------------------ the stem: 7x7, stride 2
 // models/layers_transposed.py:78-87 (Backbone.conv1 + bn1 + LeakyReLU): Conv2d(3, 64, 7, stride 2, padding 3) on the NHWC
 // image.  MIOpen ran it as an implicit GEMM plus a separate bias / activation pass plus a layout copy (4.0 ms of a 176 ms
@@ -909,7 +1091,7 @@ __global__ __launch_bounds__(256) void k_stem7x7(const StemParams p) {
         // ---- epilogue from registers: bias + LeakyReLU, 16-byte stores (epilogue_store)
         ConvParams e;
         e.bias = p.bias, e.extra = nullptr, e.extra2 = nullptr, e.y = p.y, e.y2 = nullptr;
-        e.K = 64, e.mode = 0, e.slope = p.slope;
+        e.K = 64, e.ldy = 64, e.mode = 0, e.slope = p.slope;
         const int oy = oy0 + wave;
         epilogue_store<4, 4>(acc, e, lane, 0, [&](int i) -> long {
             const int ox = ox0 + 16 * i + pl;
@@ -938,6 +1120,53 @@ int launch_stem(const StemParams &p, hipStream_t st) {
 }  // namespace
 
 extern "C" {
+
+// y = act(conv1x1(x * scale[n]) + bias (+ extra)) [, y2 = y + extra2]: see k_pw.  x: DEVICE (m, c_in) fp16 (an NHWC activation,
+// m = n * h * w pixels); scale: DEVICE (m / hw, c_in) fp16 or NULL; w: DEVICE (c_out, c_in); bias fp16[c_out]; extra / extra2 /
+// y2: DEVICE (m, c_out) or NULL; y: DEVICE, pixel stride ldy >= c_out.  extra_mode as pp_conv_own_ex_f16 (0, 1, 2, 4).
+// c_in in {64, 128, 192, 256, 384, 512}, c_out % 64 == 0, hw % 32 == 0 when scale is given; PP_ERR_UNSUPPORTED otherwise.
+PP_API int pp_pw_supported(int c_in, int c_out) {
+    return ((c_in == 64 || c_in == 128 || c_in == 192 || c_in == 256 || c_in == 384 || c_in == 512) && c_out % 64 == 0 && c_out >= 64) ? 1 : 0;
+}
+PP_API int pp_pw_f16(const void *x, const void *scale, const void *w, const void *bias, const void *extra, const void *extra2, void *y,
+                     void *y2, long m, int hw, int c_in, int c_out, int ldy, int extra_mode, float slope, void *stream) {
+    if (!x || !w || !bias || !y || m <= 0 || hw <= 0 || ldy < c_out || extra_mode < 0 || extra_mode == 3 || extra_mode > 4 ||
+        (extra_mode != 0) != (extra != nullptr) || (extra_mode == 4) != (extra2 != nullptr) || (extra_mode == 4) != (y2 != nullptr))
+        return PP_ERR_BAD_ARG;
+    if (!pp_pw_supported(c_in, c_out) || !(slope >= 0.f && slope <= 1.f) || (ldy & 7)) return PP_ERR_UNSUPPORTED;
+    if (scale && (hw & 63)) return PP_ERR_UNSUPPORTED;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(bias) |
+                         reinterpret_cast<uintptr_t>(extra) | reinterpret_cast<uintptr_t>(extra2) | reinterpret_cast<uintptr_t>(y) |
+                         reinterpret_cast<uintptr_t>(y2) | reinterpret_cast<uintptr_t>(scale);
+    if (al & 15) return PP_ERR_BAD_ARG;
+    PwParams p;
+    p.x = static_cast<const _Float16 *>(x);
+    p.scale = static_cast<const _Float16 *>(scale);
+    p.w = static_cast<const _Float16 *>(w);
+    p.e.bias = static_cast<const _Float16 *>(bias);
+    p.e.extra = static_cast<const _Float16 *>(extra);
+    p.e.extra2 = static_cast<const _Float16 *>(extra2);
+    p.e.y = static_cast<_Float16 *>(y);
+    p.e.y2 = static_cast<_Float16 *>(y2);
+    p.e.K = c_out, p.e.ldy = ldy, p.e.mode = extra_mode, p.e.slope = slope;
+    p.M = m, p.Kin = c_in, p.hw = hw;
+    // output channels per workgroup: all of them when their weights fit LDS (144 KiB), else the fewest equal splits that do
+    int n_split = 1;
+    while ((c_out / n_split) * c_in * 2 > 144 * 1024 || c_out % n_split || (c_out / n_split) % 64) {
+        if (++n_split > c_out / 64) return PP_ERR_UNSUPPORTED;
+    }
+    p.n_per_wg = c_out / n_split;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (c_in / 32) {
+        case 2: return launch_pw_inst<2>(p, n_split, st);
+        case 4: return launch_pw_inst<4>(p, n_split, st);
+        case 6: return launch_pw_inst<6>(p, n_split, st);
+        case 8: return launch_pw_inst<8>(p, n_split, st);
+        case 12: return launch_pw_inst<12>(p, n_split, st);
+        case 16: return launch_pw_inst<16>(p, n_split, st);
+        default: return PP_ERR_UNSUPPORTED;
+    }
+}
 
 // The stem of the IMHN (models/layers_transposed.py:78-87): y = leaky(conv7x7_stride2_pad3(x, w) + bias) on the NHWC image.
 // x: DEVICE (n, h, w, 3) fp16 with h, w even and w % 4 == 0; w_prepared: DEVICE (64, 192) fp16 in the kernel's k order -- row r
@@ -1023,6 +1252,7 @@ PP_API int pp_conv_own_ex_f16(const void *x, const void *w, const void *bias, co
     p.y2 = static_cast<_Float16 *>(y2);
     p.zero = ds->zero;
     p.N = n; p.H = h; p.W = wd; p.C = c_in; p.K = c_out; p.R = ksize; p.pad = pad; p.dil = dilation; p.Ho = ho; p.Wo = wo;
+    p.ldy = c_out;
     p.M = (long)n * ho * wo;
     p.mode = extra_mode;
     p.slope = slope;

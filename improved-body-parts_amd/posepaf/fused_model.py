@@ -37,6 +37,8 @@ USE_FUSED_CONV = True
 USE_OWN_CONV = True
 TUNE_MIOPEN = os.environ.get("POSEPAF_TUNE_MIOPEN", "0") == "1"   # also time MIOpen + epilogue pass where fused kernels exist
 OWN_VARIANTS = {101: 256, 102: 128, 103: 64, 104: 512}
+PW_VARIANT = 105            # the streaming 1x1 kernel (pp_pw_f16): weights resident in LDS, pixel fragments straight from HBM
+USE_PW = True
 _conv_choice: dict = {}   # shape key -> tile configuration id, or -1 = MIOpen convolution + k_bias_act pass
 _conv_timing: dict = {}   # shape key -> {"miopen": ms, cfg: ms, ...} measured by the autotune (diagnostics)
 _conv_calls: dict = {}    # shape key -> number of forward() calls since import (diagnostics)
@@ -263,6 +265,18 @@ def _fold(conv: nn.Conv2d, bn: nn.BatchNorm2d | None):
     return w, b
 
 
+class Scaled:
+    """An activation together with its SE gains (models/layers_transposed.py:289-310: out = y * s[n, c]) NOT yet multiplied:
+    the 1x1 convolutions that consume it multiply in their input read (pp_pw_f16's `scale`), so the separate x * s pass over
+    the feature map is never made.  materialize() is that pass, for consumers that cannot fold it."""
+
+    def __init__(self, y, s):
+        self.y, self.s = y, s
+
+    def materialize(self):
+        return channel_scale(self.y, self.s)
+
+
 class FConv(nn.Module):
     """conv + folded-BN bias [+ LeakyReLU]"""
 
@@ -294,6 +308,12 @@ class FConv(nn.Module):
     def _fused_launch(self, cfg, x, extra, mode, y):
         from . import _lib
         n, c, h, w = x.shape
+        if cfg == PW_VARIANT:
+            if self.weight.shape[2] != 1 or self.padding[0] != 0:
+                return -6
+            return _lib.load().pp_pw_f16(_ptr(x), None, _ptr(self.weight), _ptr(self.bias), _ptr(extra), None, _ptr(y), None,
+                                         n * h * w, h * w, c, self.weight.shape[0], y.stride(3), mode, LEAK if self.act else 1.0,
+                                         _stream(x))
         if cfg >= 100:   # hand-written kernels (csrc/posepaf_conv_own.hip): workgroup-tile variant OWN_VARIANTS[cfg]
             return _lib.load().pp_conv_own_f16(_ptr(x), _ptr(self.weight), _ptr(self.bias), _ptr(extra), _ptr(y), n, h, w, c,
                                                self.weight.shape[0], self.weight.shape[2], self.padding[0], self.dilation[0], mode,
@@ -348,6 +368,8 @@ class FConv(nn.Module):
         best, best_t, times = -1, float("inf"), {}
         own = [c_ for c_ in OWN_VARIANTS if USE_OWN_CONV and L.pp_conv_own_supported(x.shape[1], self.weight.shape[0],
                                                                                      self.weight.shape[2])]
+        if USE_PW and USE_OWN_CONV and self.weight.shape[2] == 1 and L.pp_pw_supported(x.shape[1], self.weight.shape[0]):
+            own = own + [PW_VARIANT]
         for cfg in list(range(L.pp_conv_num_configs())) + own:
             if self._fused_launch(cfg, x, extra, mode, y) != 0:
                 continue
@@ -428,17 +450,20 @@ class FConv(nn.Module):
     # ---- two outputs: y = act(conv(x) + bias + res) and y + other, one launch of an own kernel (pp_conv_own_ex_f16 mode 4)
     def forward_dual(self, x, res, other):
         """-> (y, y + other) with y = act(conv(x) + bias + res).  One launch with two stores when that beats the fused
-        convolution followed by a tensor add, timed once per shape."""
+        convolution followed by a tensor add, timed once per shape.  x may be a Scaled pair (activation, SE gains)."""
         from . import _lib
+        scale = None
+        if isinstance(x, Scaled):
+            x, scale = x.y, x.s
         n, c, h, w = x.shape
         k, r = self.weight.shape[0], self.weight.shape[2]
-        key = ("dual", n, c, h, w, k, r, self.padding[0], self.dilation[0], bool(self.act))
+        key = ("dual", n, c, h, w, k, r, self.padding[0], self.dilation[0], bool(self.act), scale is not None)
         ok = (USE_OWN_CONV and x.is_cuda and x.dtype == torch.float16 and self.stride == (1, 1) and res is not None
               and self.weight.shape[2] == self.weight.shape[3] and self.padding[0] == self.padding[1] and self.dilation[0] == self.dilation[1]
               and 2 * self.padding[0] == self.dilation[0] * (r - 1) and _lib.load().pp_conv_own_supported(c, k, r))
 
         def separate():
-            y = self(x, res)
+            y = self(x if scale is None else channel_scale(x, scale), res)
             return y, y + other
 
         def fused(bn):
@@ -447,6 +472,14 @@ class FConv(nn.Module):
                 self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
             y = torch.empty((n, k, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
             y2 = torch.empty_like(y, memory_format=torch.channels_last)
+            if bn == PW_VARIANT:   # the streaming 1x1 kernel, optionally with the SE gains of `x` folded into its input read
+                if not (USE_PW and r == 1 and self.padding[0] == 0 and _lib.load().pp_pw_supported(c, k)):
+                    return None
+                rc = _lib.load().pp_pw_f16(_ptr(xx), _ptr(scale), _ptr(self.weight), _ptr(self.bias), _ptr(rr), _ptr(oo), _ptr(y),
+                                           _ptr(y2), n * h * w, h * w, c, k, k, 4, LEAK if self.act else 1.0, _stream(x))
+                return (y, y2) if rc == 0 else None
+            if scale is not None:
+                return None
             rc = _lib.load().pp_conv_own_ex_f16(_ptr(xx), _ptr(self.weight), _ptr(self.bias), _ptr(rr), _ptr(oo), _ptr(y), _ptr(y2), n, h, w,
                                                 c, k, r, self.padding[0], self.dilation[0], 4, LEAK if self.act else 1.0, bn, 0, _stream(x))
             return (y, y2) if rc == 0 else None
@@ -471,8 +504,10 @@ class FConv(nn.Module):
                 return sorted(ts)[len(ts) // 2]
             times = {"separate": timed(separate)}
             choice, best = 0, times["separate"]
-            for bn in (256, 128, 64, 512):
-                if k % (bn if bn != 512 else 128) or fused(bn) is None:
+            for bn in (256, 128, 64, 512, PW_VARIANT):
+                if bn != PW_VARIANT and k % (bn if bn != 512 else 128):
+                    continue
+                if fused(bn) is None:
                     continue
                 times[bn] = timed(lambda: fused(bn))
                 if times[bn] < best:
@@ -486,8 +521,30 @@ class FConv(nn.Module):
                 return out
         return separate()
 
+    def forward_scaled(self, xs: "Scaled", res=None):
+        """act(conv1x1(xs.y * xs.s) + bias (+ res)) with the gains folded into the kernel's input read; None when not taken"""
+        from . import _lib
+        x, sc = _cl(xs.y), xs.s.contiguous()
+        n, c, h, w = x.shape
+        k = self.weight.shape[0]
+        if not (USE_PW and USE_OWN_CONV and x.is_cuda and x.dtype == torch.float16 and tuple(self.weight.shape[2:]) == (1, 1)
+                and self.stride == (1, 1) and self.padding == (0, 0) and (h * w) % 64 == 0 and _lib.load().pp_pw_supported(c, k)):
+            return None
+        if not self.weight.is_contiguous(memory_format=torch.channels_last):
+            self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
+        y = torch.empty((n, k, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        res = _cl(res) if res is not None else None
+        rc = _lib.load().pp_pw_f16(_ptr(x), _ptr(sc), _ptr(self.weight), _ptr(self.bias), _ptr(res), None, _ptr(y), None, n * h * w,
+                                   h * w, c, k, k, 1 if res is not None else 0, LEAK if self.act else 1.0, _stream(x))
+        return y if rc == 0 else None
+
     def forward(self, x, res=None, post=None):
         """act(conv(x) + bias (+ res)) (+ post)"""
+        if isinstance(x, Scaled):
+            y = self.forward_scaled(x, res) if post is None else None
+            if y is not None:
+                return y
+            x = x.materialize()
         if self._fused_eligible(x, res, post):
             y = self._fused(x, res, post)
             if y is not None:
@@ -539,6 +596,43 @@ class FStem(FConv):
         _lib.check(_lib.load().pp_stem7x7_f16(_ptr(x), _ptr(self.prepared), _ptr(self.bias), _ptr(y), n, h, w,
                                               LEAK if self.act else 1.0, _stream(x)))
         return y
+
+
+class FHead(FConv):
+    """The 1x1 prediction heads (256 -> 50 channels, models/posenet.py:60-66).  50 is not a multiple of the kernels' 64-channel
+    granule: weights and bias are zero-padded to 64 outputs once, the streaming 1x1 kernel writes a 64-channel tensor whose
+    channels 50..63 are exact zeros, and the caller gets the [:, :50] view of it."""
+
+    def __init__(self, conv, bn, act):
+        super().__init__(conv, bn, act)
+        k, c = self.weight.shape[:2]
+        kp = -(-k // 64) * 64
+        wpad = torch.zeros((kp, c, 1, 1), dtype=self.weight.dtype)
+        wpad[:k] = self.weight.detach()
+        bpad = torch.zeros(kp, dtype=self.bias.dtype)
+        bpad[:k] = self.bias.detach()
+        self.wpad = nn.Parameter(wpad, requires_grad=False)
+        self.bpad = nn.Parameter(bpad, requires_grad=False)
+        self.k_real = k
+
+    def forward(self, x, res=None, post=None):
+        from . import _lib
+        xs = x if isinstance(x, Scaled) else None
+        xx = _cl(xs.y if xs is not None else x)
+        n, c, h, w = xx.shape
+        kp = self.wpad.shape[0]
+        ok = (USE_PW and USE_OWN_CONV and res is None and post is None and xx.is_cuda and xx.dtype == torch.float16
+              and tuple(self.weight.shape[2:]) == (1, 1) and (xs is None or (h * w) % 64 == 0) and _lib.load().pp_pw_supported(c, kp))
+        if ok:
+            if not self.wpad.is_contiguous(memory_format=torch.channels_last):
+                self.wpad.data = self.wpad.data.contiguous(memory_format=torch.channels_last)
+            y = torch.empty((n, kp, h, w), dtype=xx.dtype, device=xx.device, memory_format=torch.channels_last)
+            rc = _lib.load().pp_pw_f16(_ptr(xx), _ptr(xs.s.contiguous()) if xs is not None else None, _ptr(self.wpad), _ptr(self.bpad),
+                                       None, None, _ptr(y), None, n * h * w, h * w, c, kp, kp, 0, LEAK if self.act else 1.0,
+                                       _stream(xx))
+            if rc == 0:
+                return y[:, : self.k_real]
+        return super().forward(xs.materialize() if xs is not None else x, res, post)
 
 
 def _fconv_from_block(m, act=None):  # models.layers_transposed.Conv / DilatedConv
@@ -594,9 +688,11 @@ class FSE(nn.Module):
         super().__init__()
         self.fc1, self.fc2 = se.fc[0], se.fc[2]
 
-    def forward(self, x):
+    def forward(self, x, fold: bool = False):
         y = channel_mean(x)
         y = torch.sigmoid(self.fc2(F.leaky_relu(self.fc1(y), 0.01)))
+        if fold and x.is_cuda and x.dtype == torch.float16 and USE_PW and USE_OWN_CONV:
+            return Scaled(x, y)            # the consumers (1x1 head / merge convolutions) multiply while they read
         return channel_scale(x, y)
 
 
@@ -605,8 +701,8 @@ class FFeature(nn.Module):
         super().__init__()
         self.c1, self.c2, self.se = _fconv_from_block(seq[0]), _fconv_from_block(seq[1]), FSE(seq[2])
 
-    def forward(self, x):
-        return self.se(self.c2(self.c1(x)))
+    def forward(self, x, fold: bool = False):
+        return self.se(self.c2(self.c1(x)), fold)
 
 
 class FusedIMHN(nn.Module):
@@ -622,7 +718,7 @@ class FusedIMHN(nn.Module):
         self.dil = nn.ModuleList([_fconv_from_block(d) for d in pre.dilation])
         self.hg = nn.ModuleList([FHourglass(h) for h in p.hourglass])
         self.feat = nn.ModuleList([nn.ModuleList([FFeature(s) for s in f.before_regress]) for f in p.features])
-        self.head = nn.ModuleList([nn.ModuleList([_fconv_from_block(c) for c in o]) for o in p.outs])
+        self.head = nn.ModuleList([nn.ModuleList([FHead(c.conv, c.bn, c.relu is not None) for c in o]) for o in p.outs])
         self.mfeat = nn.ModuleList([nn.ModuleList([_fconv_from_block(m.conv) for m in ms]) for ms in p.merge_features])
         self.mpred = nn.ModuleList([nn.ModuleList([_fconv_from_block(m.conv) for m in ms]) for ms in p.merge_preds])
         # cache_s = merge_pred(pred) + merge_feat(feat): both are bias-only 1x1 convs -> one epilogue with the summed bias
@@ -651,7 +747,9 @@ class FusedIMHN(nn.Module):
             hg = self.hg[t](x, None if caches is None else caches[0])   # scale 0 comes back with its cache added
             if caches is not None:
                 hg = [hg[0]] + [hg[s] + caches[s] for s in scales if s > 0]
-            feats = [self.feat[t][s](hg[s]) for s in scales]
+            # feats[s] stays a (feature map, SE gains) pair: its consumers -- the head and the merge convolution, both 1x1 --
+            # multiply while they read
+            feats = [self.feat[t][s](hg[s], fold=True) for s in scales]
             preds = [self.head[t][s](feats[s]) for s in scales]
             seen.append(preds[0])
             if last:

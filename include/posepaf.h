@@ -212,6 +212,18 @@ PP_API int pp_conv_own_ex_f16(const void *x, const void *w, const void *bias, co
                               int n, int h, int wd, int c_in, int c_out, int ksize, int pad, int dilation, int extra_mode, float slope,
                               int bn, int upsampled_input, void *stream);
 
+/* A1, the 1x1 convolutions as an HBM-bound stream with the neighbouring element-wise passes folded in (csrc/posepaf_conv_own.hip
+ * k_pw):   y = act(conv1x1(x * scale[n]) + bias (+ extra))   [and  y2 = y + extra2]
+ * x: DEVICE (m, c_in) fp16 = an NHWC activation of m = n * h * w pixels; scale: DEVICE (m / hw, c_in) fp16 or NULL -- the SE
+ * block's per-sample channel gains (models/layers_transposed.py:289-310), multiplied into the input in binary16 exactly as the
+ * separate x * s pass would; w: DEVICE (c_out, c_in); bias fp16[c_out]; extra / extra2 / y2: DEVICE (m, c_out) or NULL;
+ * y: DEVICE with ldy >= c_out elements between pixels (a channel slice of a wider tensor when larger); hw = h * w.
+ * extra_mode 0 / 1 / 2 / 4 as pp_conv_own_ex_f16.  pp_pw_supported: c_in in {64, 128, 192, 256, 384, 512}, c_out % 64 == 0;
+ * with `scale`, hw % 64 == 0 (a group of pixels must not straddle two images). */
+PP_API int pp_pw_supported(int c_in, int c_out);
+PP_API int pp_pw_f16(const void *x, const void *scale, const void *w, const void *bias, const void *extra, const void *extra2, void *y,
+                     void *y2, long m, int hw, int c_in, int c_out, int ldy, int extra_mode, float slope, void *stream);
+
 /* A1, the stem (models/layers_transposed.py:78-87 Backbone.conv1 + bn1 + LeakyReLU): y = leaky(conv(x, w, 7x7, stride 2, padding 3)
  * + bias) in one HBM-bound pass.  x: DEVICE (n, h, w, 3) NHWC fp16, h even, w % 4 == 0; w_prepared: DEVICE (64, 192) fp16,
  * w_prepared[k][(r * 8 + s1) * 3 + c] = weight[k][c][r][s1 - 1] (zeros for s1 = 0 and past 168); bias fp16[64];

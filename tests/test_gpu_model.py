@@ -114,6 +114,77 @@ def test_stem_kernel_matches_torch(shape):
     assert err <= 2e-3 * max(1.0, ref.abs().max().item()), (shape, err)
 
 
+@pytest.mark.parametrize("shape", [
+    # n, h, w, c_in, c_out
+    (2, 16, 32, 128, 256),      # weights 64 KB: two workgroups per CU
+    (3, 8, 8, 256, 256),        # 128 KB of weights: one workgroup per CU; 192 pixels = 6 groups
+    (1, 8, 12, 256, 640),       # C_out split over five workgroup columns (640 x 256 x 2 B > LDS)
+    (2, 5, 7, 64, 64),          # 70 pixels: a ragged last group (no scale: hw % 64 != 0); narrow input: 64-pixel groups
+    (1, 16, 16, 384, 192),      # 144 KB of weights
+    (2, 8, 16, 512, 128),
+    (1, 32, 32, 192, 384),
+])
+def test_streaming_pointwise_convolution_matches_torch(shape):
+    """pp_pw_f16 (csrc/posepaf_conv_own.hip k_pw): y = act(conv1x1(x * scale[n]) + bias (+ extra)) [, y2 = y + extra2] against fp32
+    torch on the same fp16 operands -- every epilogue mode, the SE gains folded into the input read (must equal the convolution
+    of the fp16-rounded x * s tensor), a strided output (channel slice of a wider tensor), C_out splits, ragged pixel counts."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from posepaf import _lib
+    L = _lib.load()
+    n, h, w, ci, co = shape
+    assert L.pp_pw_supported(ci, co)
+    g = torch.Generator(device="cpu").manual_seed(41)
+    x = torch.randn(n, ci, h, w, generator=g).cuda().half().contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(co, ci, 1, 1, generator=g) / ci ** 0.5).cuda().half().contiguous(memory_format=torch.channels_last)
+    b = torch.randn(co, generator=g).cuda().half()
+    ex = torch.randn(n, co, h, w, generator=g).cuda().half().contiguous(memory_format=torch.channels_last)
+    ex2 = torch.randn(n, co, h, w, generator=g).cuda().half().contiguous(memory_format=torch.channels_last)
+    sc = (0.2 + torch.rand(n, ci, generator=g)).cuda().half()
+    vp = C.c_void_p
+    st = vp(torch.cuda.current_stream().cuda_stream)
+    m, hw = n * h * w, h * w
+    for use_scale in ([False, True] if hw % 64 == 0 else [False]):
+        xin = (x * sc[:, :, None, None]) if use_scale else x          # the fp16 tensor the separate SE pass would have written
+        conv = F.conv2d(xin.float(), wt.float(), b.float())
+        for mode, slope in [(0, 0.01), (1, 0.01), (2, 0.01), (0, 1.0), (4, 1.0)]:
+            ref = conv + ex.float() if mode in (1, 4) else conv
+            ref = F.leaky_relu(ref, slope) if slope != 1.0 else ref
+            ref = ref + ex.float() if mode == 2 else ref
+            wide = torch.full((n, co + 64, h, w), float("nan"), dtype=torch.float16, device="cuda").contiguous(memory_format=torch.channels_last)
+            y = wide[:, 32:32 + co]                                    # a channel slice: pixel stride co + 64
+            y2 = torch.full((n, co, h, w), float("nan"), dtype=torch.float16, device="cuda").contiguous(memory_format=torch.channels_last)
+            rc = L.pp_pw_f16(vp(x.data_ptr()), vp(sc.data_ptr()) if use_scale else None, vp(wt.data_ptr()), vp(b.data_ptr()),
+                             vp(ex.data_ptr()) if mode else None, vp(ex2.data_ptr()) if mode == 4 else None, vp(y.data_ptr()),
+                             vp(y2.data_ptr()) if mode == 4 else None, m, hw, ci, co, co + 64, mode, slope, st)
+            assert rc == 0, (shape, mode, rc)
+            torch.cuda.synchronize()
+            assert torch.isfinite(y).all() and torch.isnan(wide[:, :32]).all() and torch.isnan(wide[:, 32 + co:]).all()
+            err = (y.float() - ref).abs().max().item()
+            assert err <= 2e-3 * max(1.0, ref.abs().max().item()), (shape, use_scale, mode, err)
+            if mode == 4:
+                assert torch.equal(y2, (y.float() + ex2.float()).half())   # the exact sum of the two binary16 tensors, rounded once
+    assert L.pp_pw_f16(vp(x.data_ptr()), None, vp(wt.data_ptr()), vp(b.data_ptr()), None, None, vp(x.data_ptr()), None, m, hw, 96, co,
+                       co, 0, 0.01, st) == -6                            # an input width the kernel has no instance for
+
+
+def test_se_gains_folded_into_the_consumers_keep_the_model_output():
+    """FusedIMHN with the SE gains folded into the head / merge convolutions' input read (Scaled + pp_pw_f16) against the same
+    model with the separate x * s pass (USE_PW = False): same arithmetic up to the accumulation order of the 1x1 kernels."""
+    from posepaf import fused_model as fm
+    model = fm.build_inference_model(torch.device("cuda"), fused=True)
+    x = torch.from_numpy(np.random.default_rng(9).random((2, 128, 128, 3), dtype=np.float32)).cuda().half()
+    with torch.no_grad():
+        fm.USE_PW = False
+        try:
+            a = model(x).float()
+        finally:
+            fm.USE_PW = True
+        b = model(x).float()
+    assert a.shape == b.shape == (2, 50, 32, 32)
+    assert (a - b).abs().max().item() <= 0.01 * a.abs().max().item()
+
+
 def test_pipeline_end_to_end_runs():
     """uint8 images -> records through the real architecture.  (Bitwise run-to-run equality is NOT asserted here:
     MIOpen may pick a different convolution algorithm on a shape's first call and some of its fp16 kernels

@@ -42,6 +42,13 @@ print(f"sum over tuned shapes: {tot:.2f} ms per forward")
 print("all configurations, ms (top 8 shapes):")
 for tt, key, calls, best, t, tm, tf, gb in rows[:8]:
     print(key, {k: round(v, 3) for k, v in fm._conv_timing[key].items()})
+print("1x1 shapes, every candidate (ms; 105 = the streaming 1x1 kernel, 101-103 = implicit GEMM, 0-9 = composable_kernel templates):")
+for tt, key, calls, best, t, tm, tf, gb in rows:
+    if key[5] == 1:
+        tms = fm._conv_timing[key]
+        ck = min([v for k_, v in tms.items() if isinstance(k_, int) and k_ < 100] or [float("nan")])
+        print(f"  {key[1]:4d}->{key[4]:4d} @{key[2]}x{key[3]} mode {key[8]}: best ck {ck:.3f}  pw {tms.get(105, float('nan')):.3f}  igemm "
+              f"{min([v for k_, v in tms.items() if isinstance(k_, int) and 101 <= k_ <= 103] or [float('nan')]):.3f}  -> {best}")
 print("upsample x2 -> 3x3 convolution -> add(s): separate launches vs one launch of the halo kernel, ms")
 for key, t in up2.items():
     _, n, c, h, w, k, two, act = key
