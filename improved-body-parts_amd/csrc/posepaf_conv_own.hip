@@ -140,9 +140,25 @@ __device__ __forceinline__ void epilogue_body(const float4_t (&acc)[PT][CT], con
 // The same epilogue with the `extra` / `extra2` vectors ALREADY in registers (k_pw requests them before its MFMAs, so their
 // latency hides under the matrix work instead of following it): pre[i][jp / 2] / pre2[...] = the 16 bytes this lane adds to
 // pixel tile i, channel-tile pair jp.  Same arithmetic, same stores as epilogue_body.
-template <int MODE, int PT, int CT, typename PixelOf>
+// POOL: the group is a 2-row block (tiles 0 .. PT/2-1 = row y, tiles PT/2 .. = row y + 1, same columns) and the 2x2 max-pool of
+// the tensor just produced (y, or y2 in mode 4) goes out as well -- `low = lv[1](pool(x))` of the hourglass
+// (models/layers_transposed.py:262-266) finds its input without a pooling pass: vertical pairs are two registers of one lane,
+// horizontal pairs are neighbouring lanes (same channels).  pool_base: index of the group's first pooled pixel.
+__device__ __forceinline__ half8_t lane_xor1(const half8_t &v) {
+    union {
+        half8_t h;
+        int u[4];
+    } a, b;
+    a.h = v;
+#pragma unroll
+    for (int k = 0; k < 4; k++) b.u[k] = __shfl_xor(a.u[k], 1);
+    return b.h;
+}
+
+template <int MODE, int PT, int CT, bool POOL, typename PixelOf>
 __device__ __forceinline__ void epilogue_preloaded(const float4_t (&acc)[PT][CT], const ConvParams &p, int lane, int nbase,
-                                                   PixelOf pixel_of, const half8_t (&pre)[PT][CT / 2], const half8_t (&pre2)[PT][CT / 2]) {
+                                                   PixelOf pixel_of, const half8_t (&pre)[PT][CT / 2], const half8_t (&pre2)[PT][CT / 2],
+                                                   _Float16 *pool = nullptr, long pool_base = 0) {
     const int g = lane >> 4, odd = g & 1, cbase = (g & ~1) * 4;
     const float2_t slope2 = float2_t{p.slope, p.slope};
 #pragma unroll
@@ -152,6 +168,7 @@ __device__ __forceinline__ void epilogue_preloaded(const float4_t (&acc)[PT][CT]
         float2_t b2[4];
 #pragma unroll
         for (int e = 0; e < 4; e++) b2[e] = float2_t{(float)bv[2 * e], (float)bv[2 * e + 1]};
+        half8_t keep[PT];
 #pragma unroll
         for (int i = 0; i < PT; i++) {
             float v[8];
@@ -163,6 +180,7 @@ __device__ __forceinline__ void epilogue_preloaded(const float4_t (&acc)[PT][CT]
                 v[4 + e] = __builtin_bit_cast(float, (unsigned)sw[1]);
             }
             const long m = pixel_of(i);
+            keep[i] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
             if (m >= 0) {
                 const half8_t ev = pre[i][jp / 2], ev2 = pre2[i][jp / 2];
                 half8_t out, out2;
@@ -183,6 +201,16 @@ __device__ __forceinline__ void epilogue_preloaded(const float4_t (&acc)[PT][CT]
                 }
                 *reinterpret_cast<half8_t *>(p.y + (m * p.ldy + co)) = out;
                 if (MODE == 4) *reinterpret_cast<half8_t *>(p.y2 + (m * p.K + co)) = out2;
+                keep[i] = MODE == 4 ? out2 : out;
+            }
+        }
+        if (POOL) {
+            constexpr int CB = PT / 2;
+#pragma unroll
+            for (int cb = 0; cb < CB; cb++) {
+                const half8_t vert = __builtin_elementwise_max(keep[cb], keep[CB + cb]);
+                const half8_t pm = __builtin_elementwise_max(vert, lane_xor1(vert));
+                if (!(lane & 1)) *reinterpret_cast<half8_t *>(pool + ((pool_base + cb * 8 + ((lane & 15) >> 1)) * p.K + co)) = pm;
             }
         }
     }
@@ -898,6 +926,8 @@ struct PwParams {
     ConvParams e;          // bias, extra, extra2, y, y2, K (= C_out), ldy, mode, slope: the shared epilogue's view
     long M;                // pixels
     int Kin, hw, n_per_wg; // input channels, pixels per image (scale index), output channels per workgroup
+    _Float16 *pool;        // NULL, or the 2x2 max-pool of the produced tensor (m / 4 pixels x C_out): groups are then 2-row blocks
+    int W;                 // pixels per image row (pool mode)
 };
 
 // PT: 16-pixel tiles per wave and group (2: 32 pixels; 4: 64 pixels for the narrow inputs, whose groups are otherwise too small
@@ -920,13 +950,22 @@ __global__ __launch_bounds__(512) void k_pw(const PwParams p) {
     const int wfrag = (lane & 15) * 64 + (((lane >> 4) * 16) ^ (((lane & 15) >> 3) << 5));
     const int g = lane >> 4, pl = lane & 15;
     constexpr int GP = PT * 16;   // pixels per group
+    constexpr int CB = PT / 2;    // pool mode: 16-pixel column blocks per group (the group is 2 rows x 16 CB columns)
+    const bool pooling = p.pool != nullptr;
     const long groups = (p.M + GP - 1) / GP;
+    const int cblocks = pooling ? p.W / (16 * CB) : 1;   // groups per row pair
     for (long grp = (long)blockIdx.x * 8 + wave; grp < groups; grp += (long)gridDim.x * 8) {
-        const long m0 = grp * GP;
+        // pixel index of tile i's lane-0 pixel: consecutive pixels, or (pool mode) row 2 rp + i / CB, column block i % CB
+        const long rp = pooling ? grp / cblocks : 0;
+        const int cbk = pooling ? (int)(grp - rp * cblocks) : 0;
+        auto tile_m = [&](int i) -> long {
+            return pooling ? (2 * rp + i / CB) * p.W + (long)(cbk * CB + i % CB) * 16 : grp * GP + 16 * i;
+        };
+        const long m0 = tile_m(0);
         half8_t xf[PT][KT];
 #pragma unroll
         for (int i = 0; i < PT; i++) {
-            const long m = m0 + 16 * i + pl;
+            const long m = tile_m(i) + pl;
             const _Float16 *row = p.x + (m < p.M ? m : 0) * (KT * 32) + g * 8;
 #pragma unroll
             for (int t = 0; t < KT; t++) xf[i][t] = *reinterpret_cast<const half8_t *>(row + t * 32);
@@ -953,7 +992,7 @@ __global__ __launch_bounds__(512) void k_pw(const PwParams p) {
                 const int gg = lane >> 4, odd = gg & 1, cbase = (gg & ~1) * 4;
 #pragma unroll
                 for (int i = 0; i < PT; i++) {
-                    const long m = m0 + 16 * i + pl;
+                    const long m = tile_m(i) + pl;
                     const long mm = m < p.M ? m : 0;
 #pragma unroll
                     for (int jp = 0; jp < 2; jp++) {
@@ -974,13 +1013,19 @@ __global__ __launch_bounds__(512) void k_pw(const PwParams p) {
                 }
             }
             auto pix = [&](int i) -> long {
-                const long m = m0 + 16 * i + pl;
+                const long m = tile_m(i) + pl;
                 return m < p.M ? m : -1;
             };
-            if (p.e.mode == 0) epilogue_preloaded<0, PT, 4>(acc, p.e, lane, n_base + c0, pix, pre, pre2);
-            else if (p.e.mode == 1) epilogue_preloaded<1, PT, 4>(acc, p.e, lane, n_base + c0, pix, pre, pre2);
-            else if (p.e.mode == 2) epilogue_preloaded<2, PT, 4>(acc, p.e, lane, n_base + c0, pix, pre, pre2);
-            else epilogue_preloaded<4, PT, 4>(acc, p.e, lane, n_base + c0, pix, pre, pre2);
+            if (pooling) {
+                const long pb = rp * (p.W >> 1) + (long)cbk * CB * 8;   // the group's first pooled pixel
+                if (p.e.mode == 0) epilogue_preloaded<0, PT, 4, true>(acc, p.e, lane, n_base + c0, pix, pre, pre2, p.pool, pb);
+                else if (p.e.mode == 1) epilogue_preloaded<1, PT, 4, true>(acc, p.e, lane, n_base + c0, pix, pre, pre2, p.pool, pb);
+                else if (p.e.mode == 2) epilogue_preloaded<2, PT, 4, true>(acc, p.e, lane, n_base + c0, pix, pre, pre2, p.pool, pb);
+                else epilogue_preloaded<4, PT, 4, true>(acc, p.e, lane, n_base + c0, pix, pre, pre2, p.pool, pb);
+            } else if (p.e.mode == 0) epilogue_preloaded<0, PT, 4, false>(acc, p.e, lane, n_base + c0, pix, pre, pre2);
+            else if (p.e.mode == 1) epilogue_preloaded<1, PT, 4, false>(acc, p.e, lane, n_base + c0, pix, pre, pre2);
+            else if (p.e.mode == 2) epilogue_preloaded<2, PT, 4, false>(acc, p.e, lane, n_base + c0, pix, pre, pre2);
+            else epilogue_preloaded<4, PT, 4, false>(acc, p.e, lane, n_base + c0, pix, pre, pre2);
         }
     }
 }
@@ -1128,8 +1173,26 @@ extern "C" {
 PP_API int pp_pw_supported(int c_in, int c_out) {
     return ((c_in == 64 || c_in == 128 || c_in == 192 || c_in == 256 || c_in == 384 || c_in == 512) && c_out % 64 == 0 && c_out >= 64) ? 1 : 0;
 }
+static int pw_run(const void *x, const void *scale, const void *w, const void *bias, const void *extra, const void *extra2, void *y,
+                  void *y2, long m, int hw, int c_in, int c_out, int ldy, int extra_mode, float slope, void *pool, int width, void *stream);
+
 PP_API int pp_pw_f16(const void *x, const void *scale, const void *w, const void *bias, const void *extra, const void *extra2, void *y,
                      void *y2, long m, int hw, int c_in, int c_out, int ldy, int extra_mode, float slope, void *stream) {
+    return pw_run(x, scale, w, bias, extra, extra2, y, y2, m, hw, c_in, c_out, ldy, extra_mode, slope, nullptr, 0, stream);
+}
+
+// The same with the 2x2 / stride 2 max-pool of the produced tensor (y; y2 in mode 4) as one more output: pool_out DEVICE
+// (m / 4, c_out) = (n, h / 2, w / 2, c_out); width = w (pixels per row), a multiple of 32 (64 for c_in = 64), h even.
+PP_API int pp_pw_pool_f16(const void *x, const void *scale, const void *w, const void *bias, const void *extra, const void *extra2,
+                          void *y, void *y2, void *pool_out, long m, int hw, int width, int c_in, int c_out, int ldy, int extra_mode,
+                          float slope, void *stream) {
+    if (!pool_out || width <= 0 || hw % width || ((hw / width) & 1) || (reinterpret_cast<uintptr_t>(pool_out) & 15)) return PP_ERR_BAD_ARG;
+    if (width % (c_in == 64 ? 64 : 32) || m % hw) return PP_ERR_UNSUPPORTED;
+    return pw_run(x, scale, w, bias, extra, extra2, y, y2, m, hw, c_in, c_out, ldy, extra_mode, slope, pool_out, width, stream);
+}
+
+static int pw_run(const void *x, const void *scale, const void *w, const void *bias, const void *extra, const void *extra2, void *y,
+                  void *y2, long m, int hw, int c_in, int c_out, int ldy, int extra_mode, float slope, void *pool, int width, void *stream) {
     if (!x || !w || !bias || !y || m <= 0 || hw <= 0 || ldy < c_out || extra_mode < 0 || extra_mode == 3 || extra_mode > 4 ||
         (extra_mode != 0) != (extra != nullptr) || (extra_mode == 4) != (extra2 != nullptr) || (extra_mode == 4) != (y2 != nullptr))
         return PP_ERR_BAD_ARG;
@@ -1150,6 +1213,7 @@ PP_API int pp_pw_f16(const void *x, const void *scale, const void *w, const void
     p.e.y2 = static_cast<_Float16 *>(y2);
     p.e.K = c_out, p.e.ldy = ldy, p.e.mode = extra_mode, p.e.slope = slope;
     p.M = m, p.Kin = c_in, p.hw = hw;
+    p.pool = static_cast<_Float16 *>(pool), p.W = width;
     // output channels per workgroup: all of them when their weights fit LDS (144 KiB), else the fewest equal splits that do
     int n_split = 1;
     while ((c_out / n_split) * c_in * 2 > 144 * 1024 || c_out % n_split || (c_out / n_split) % 64) {

@@ -39,6 +39,7 @@ TUNE_MIOPEN = os.environ.get("POSEPAF_TUNE_MIOPEN", "0") == "1"   # also time MI
 OWN_VARIANTS = {101: 256, 102: 128, 103: 64, 104: 512}
 PW_VARIANT = 105            # the streaming 1x1 kernel (pp_pw_f16): weights resident in LDS, pixel fragments straight from HBM
 USE_PW = True
+USE_POOL_FUSION = True      # the hourglass' 2x2 max-pools leave the 1x1 kernel that produces their input as a second output
 _conv_choice: dict = {}   # shape key -> tile configuration id, or -1 = MIOpen convolution + k_bias_act pass
 _conv_timing: dict = {}   # shape key -> {"miopen": ms, cfg: ms, ...} measured by the autotune (diagnostics)
 _conv_calls: dict = {}    # shape key -> number of forward() calls since import (diagnostics)
@@ -52,6 +53,21 @@ _progress = None   # callable(str) or None: one line per tuned layer shape (benc
 def set_progress(fn) -> None:
     global _progress
     _progress = fn
+
+
+def _timed(fn):
+    """median of _TUNE_REPS single-call timings after one warm-up (HIP events on the current stream)"""
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(_TUNE_REPS):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return sorted(ts)[len(ts) // 2]
 
 
 def _note(key, choice) -> None:
@@ -448,7 +464,7 @@ class FConv(nn.Module):
         return separate()
 
     # ---- two outputs: y = act(conv(x) + bias + res) and y + other, one launch of an own kernel (pp_conv_own_ex_f16 mode 4)
-    def forward_dual(self, x, res, other):
+    def forward_dual(self, x, res, other, want_pool: bool = False):
         """-> (y, y + other) with y = act(conv(x) + bias + res).  One launch with two stores when that beats the fused
         convolution followed by a tensor add, timed once per shape.  x may be a Scaled pair (activation, SE gains)."""
         from . import _lib
@@ -457,14 +473,16 @@ class FConv(nn.Module):
             x, scale = x.y, x.s
         n, c, h, w = x.shape
         k, r = self.weight.shape[0], self.weight.shape[2]
-        key = ("dual", n, c, h, w, k, r, self.padding[0], self.dilation[0], bool(self.act), scale is not None)
+        pool_ok = want_pool and USE_POOL_FUSION and h % 2 == 0 and w % (64 if c == 64 else 32) == 0
+        key = ("dual", n, c, h, w, k, r, self.padding[0], self.dilation[0], bool(self.act), scale is not None, pool_ok)
         ok = (USE_OWN_CONV and x.is_cuda and x.dtype == torch.float16 and self.stride == (1, 1) and res is not None
               and self.weight.shape[2] == self.weight.shape[3] and self.padding[0] == self.padding[1] and self.dilation[0] == self.dilation[1]
               and 2 * self.padding[0] == self.dilation[0] * (r - 1) and _lib.load().pp_conv_own_supported(c, k, r))
 
         def separate():
             y = self(x if scale is None else channel_scale(x, scale), res)
-            return y, y + other
+            y2 = y + other
+            return (y, y2, maxpool2(y2)) if want_pool else (y, y2)
 
         def fused(bn):
             xx, rr, oo = _cl(x), _cl(res), _cl(other)
@@ -475,14 +493,24 @@ class FConv(nn.Module):
             if bn == PW_VARIANT:   # the streaming 1x1 kernel, optionally with the SE gains of `x` folded into its input read
                 if not (USE_PW and r == 1 and self.padding[0] == 0 and _lib.load().pp_pw_supported(c, k)):
                     return None
+                if pool_ok:   # ... and the 2x2 max-pool of y2 (the next stage's hourglass pools its input first)
+                    pooled = torch.empty((n, k, h // 2, w // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+                    rc = _lib.load().pp_pw_pool_f16(_ptr(xx), _ptr(scale), _ptr(self.weight), _ptr(self.bias), _ptr(rr), _ptr(oo),
+                                                    _ptr(y), _ptr(y2), _ptr(pooled), n * h * w, h * w, w, c, k, k, 4,
+                                                    LEAK if self.act else 1.0, _stream(x))
+                    return (y, y2, pooled) if rc == 0 else None
                 rc = _lib.load().pp_pw_f16(_ptr(xx), _ptr(scale), _ptr(self.weight), _ptr(self.bias), _ptr(rr), _ptr(oo), _ptr(y),
                                            _ptr(y2), n * h * w, h * w, c, k, k, 4, LEAK if self.act else 1.0, _stream(x))
-                return (y, y2) if rc == 0 else None
+                if rc != 0:
+                    return None
+                return (y, y2, maxpool2(y2)) if want_pool else (y, y2)
             if scale is not None:
                 return None
             rc = _lib.load().pp_conv_own_ex_f16(_ptr(xx), _ptr(self.weight), _ptr(self.bias), _ptr(rr), _ptr(oo), _ptr(y), _ptr(y2), n, h, w,
                                                 c, k, r, self.padding[0], self.dilation[0], 4, LEAK if self.act else 1.0, bn, 0, _stream(x))
-            return (y, y2) if rc == 0 else None
+            if rc != 0:
+                return None
+            return (y, y2, maxpool2(y2)) if want_pool else (y, y2)
 
         choice = _conv_choice.get(key) if ok else 0
         if choice is None:
@@ -537,6 +565,53 @@ class FConv(nn.Module):
         rc = _lib.load().pp_pw_f16(_ptr(x), _ptr(sc), _ptr(self.weight), _ptr(self.bias), _ptr(res), None, _ptr(y), None, n * h * w,
                                    h * w, c, k, k, 1 if res is not None else 0, LEAK if self.act else 1.0, _stream(x))
         return y if rc == 0 else None
+
+    def forward_pool(self, x, res=None):
+        """-> (y, maxpool2(y)) with y = act(conv(x) + bias (+ res)).  For a 1x1 convolution the pooled tensor can leave the
+        streaming kernel as one more output (pp_pw_pool_f16) instead of a pass of its own; timed once per shape against
+        convolution + k_maxpool2."""
+        from . import _lib
+        n, c, h, w = x.shape
+        k = self.weight.shape[0]
+        key = ("pool", n, c, h, w, k, res is not None, bool(self.act))
+        ok = (USE_PW and USE_POOL_FUSION and USE_OWN_CONV and x.is_cuda and x.dtype == torch.float16 and self.stride == (1, 1)
+              and tuple(self.weight.shape[2:]) == (1, 1) and self.padding == (0, 0) and h % 2 == 0
+              and w % (64 if c == 64 else 32) == 0 and _lib.load().pp_pw_supported(c, k))
+
+        def separate():
+            y = self(x, res)
+            return y, maxpool2(y)
+
+        def fused():
+            xx = _cl(x)
+            rr = _cl(res) if res is not None else None
+            if not self.weight.is_contiguous(memory_format=torch.channels_last):
+                self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
+            y = torch.empty((n, k, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            pooled = torch.empty((n, k, h // 2, w // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            rc = _lib.load().pp_pw_pool_f16(_ptr(xx), None, _ptr(self.weight), _ptr(self.bias), _ptr(rr), None, _ptr(y), None,
+                                            _ptr(pooled), n * h * w, h * w, w, c, k, k, 1 if res is not None else 0,
+                                            LEAK if self.act else 1.0, _stream(x))
+            return (y, pooled) if rc == 0 else None
+
+        choice = _conv_choice.get(key) if ok else 0
+        if choice is None:
+            if torch.cuda.is_current_stream_capturing():
+                return separate()
+            separate()                      # tunes the plain convolution's shape first
+            if fused() is None:
+                choice = 0
+            else:
+                t_sep, t_fused = _timed(separate), _timed(fused)
+                _conv_timing[key] = {"separate": t_sep, "fused": t_fused}
+                choice = 1 if t_fused < t_sep else 0
+            _conv_choice[key] = choice
+            _note(key, choice)
+        if choice:
+            out = fused()
+            if out is not None:
+                return out
+        return separate()
 
     def forward(self, x, res=None, post=None):
         """act(conv(x) + bias (+ res)) (+ post)"""
@@ -655,6 +730,11 @@ class FResidual(nn.Module):
         res = self.skip.conv_only(x) if self.skip is not None else x
         return self.c3(self.c2(self.c1(x)), res)
 
+    def forward_pool(self, x):
+        """-> (block output, its 2x2 max-pool): the pooled tensor leaves the block's last 1x1 convolution as a second output"""
+        res = self.skip.conv_only(x) if self.skip is not None else x
+        return self.c3.forward_pool(self.c2(self.c1(x)), res)
+
 
 class FHourglass(nn.Module):
     def __init__(self, hg):
@@ -667,19 +747,24 @@ class FHourglass(nn.Module):
                 mods.append(FResidual(hg.hg[i][4]))
             self.levels.append(nn.ModuleList(mods))
 
-    def _level(self, i, x, coarse, cache0=None):
+    def _level(self, i, x, coarse, cache0=None, pooled=None):
+        """pooled: maxpool2(x) when the producer of x already made it (pp_pw_pool_f16), else None"""
         lv = self.levels[i]
         up1 = lv[0](x)
-        low = lv[1](maxpool2(x))
-        low = lv[4](low) if i == self.depth - 1 else self._level(i + 1, low, coarse)
+        pooled = maxpool2(x) if pooled is None else pooled
+        if i == self.depth - 1:
+            low = lv[4](lv[1](pooled))
+        else:   # the next level pools this block's output first: let the block hand it over
+            low, low_pooled = lv[1].forward_pool(pooled)
+            low = self._level(i + 1, low, coarse, None, low_pooled)
         coarse.append(low)
         # up1 + act(conv(upsample(low)) + b) (+ cache at the top level of stages 2..): one launch when the halo kernel takes it
         return lv[3].forward_up2(lv[2](low), up1, cache0)
 
-    def forward(self, x, cache0=None):
+    def forward(self, x, cache0=None, pooled=None):
         """-> [top (+ cache0 when given), coarse levels...]"""
         coarse = []
-        top = self._level(0, x, coarse, cache0)
+        top = self._level(0, x, coarse, cache0, pooled)
         return [top] + coarse[::-1]
 
 
@@ -735,16 +820,16 @@ class FusedIMHN(nn.Module):
         seen = []
         x = imgs.permute(0, 3, 1, 2)  # NHWC storage viewed as NCHW == channels_last: no copy
         x = self.stem(x)
-        x = self.res2(maxpool2(self.res1(x)))
+        x = self.res2(self.res1.forward_pool(x)[1])
         d = x
         for m in self.dil:
             d = m(d)
         x = torch.cat([x, d], dim=1)
-        caches = None
+        caches, x_pooled = None, None
         for t in range(self.S):
             last = t == self.S - 1
             scales = range(1) if last else range(self.K)  # the last stage's coarse heads feed nothing
-            hg = self.hg[t](x, None if caches is None else caches[0])   # scale 0 comes back with its cache added
+            hg = self.hg[t](x, None if caches is None else caches[0], x_pooled)   # scale 0 comes back with its cache added
             if caches is not None:
                 hg = [hg[0]] + [hg[s] + caches[s] for s in scales if s > 0]
             # feats[s] stays a (feature map, SE gains) pair: its consumers -- the head and the merge convolution, both 1x1 --
@@ -755,7 +840,7 @@ class FusedIMHN(nn.Module):
             if last:
                 return seen if stage_preds else preds[0]
             # cache_s = merge_feat(feat_s) + merge_pred(pred_s); x + cache_0 leaves the scale-0 convolution as a second output
-            c0, x = self.mfeat[t][0].forward_dual(feats[0], self.mpred[t][0].conv_only(preds[0]), x)
+            c0, x, x_pooled = self.mfeat[t][0].forward_dual(feats[0], self.mpred[t][0].conv_only(preds[0]), x, want_pool=True)
             caches = [c0] + [self.mfeat[t][s](feats[s], self.mpred[t][s].conv_only(preds[s])) for s in scales if s > 0]
 
 

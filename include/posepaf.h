@@ -223,6 +223,12 @@ PP_API int pp_conv_own_ex_f16(const void *x, const void *w, const void *bias, co
 PP_API int pp_pw_supported(int c_in, int c_out);
 PP_API int pp_pw_f16(const void *x, const void *scale, const void *w, const void *bias, const void *extra, const void *extra2, void *y,
                      void *y2, long m, int hw, int c_in, int c_out, int ldy, int extra_mode, float slope, void *stream);
+/* The same with the 2x2 / stride-2 max-pool of the tensor it produces (y; y2 in mode 4) as one more output -- the hourglass pools
+ * exactly these tensors (`low = hg[i][1](pool(x))`, models/layers_transposed.py:262-266), so its pooling passes disappear.
+ * pool_out: DEVICE (n, h / 2, w / 2, c_out); width = w: a multiple of 32 (64 when c_in = 64); h even. */
+PP_API int pp_pw_pool_f16(const void *x, const void *scale, const void *w, const void *bias, const void *extra, const void *extra2,
+                          void *y, void *y2, void *pool_out, long m, int hw, int width, int c_in, int c_out, int ldy, int extra_mode,
+                          float slope, void *stream);
 
 /* A1, the stem (models/layers_transposed.py:78-87 Backbone.conv1 + bn1 + LeakyReLU): y = leaky(conv(x, w, 7x7, stride 2, padding 3)
  * + bias) in one HBM-bound pass.  x: DEVICE (n, h, w, 3) NHWC fp16, h even, w % 4 == 0; w_prepared: DEVICE (64, 192) fp16,

@@ -123,6 +123,7 @@ def test_stem_kernel_matches_torch(shape):
     (1, 16, 16, 384, 192),      # 144 KB of weights
     (2, 8, 16, 512, 128),
     (1, 32, 32, 192, 384),
+    (2, 4, 64, 64, 128),        # narrow input (64-pixel groups) with a row width the pooled form takes
 ])
 def test_streaming_pointwise_convolution_matches_torch(shape):
     """pp_pw_f16 (csrc/posepaf_conv_own.hip k_pw): y = act(conv1x1(x * scale[n]) + bias (+ extra)) [, y2 = y + extra2] against fp32
@@ -166,6 +167,26 @@ def test_streaming_pointwise_convolution_matches_torch(shape):
                 assert torch.equal(y2, (y.float() + ex2.float()).half())   # the exact sum of the two binary16 tensors, rounded once
     assert L.pp_pw_f16(vp(x.data_ptr()), None, vp(wt.data_ptr()), vp(b.data_ptr()), None, None, vp(x.data_ptr()), None, m, hw, 96, co,
                        co, 0, 0.01, st) == -6                            # an input width the kernel has no instance for
+    # the pooled second output (pp_pw_pool_f16): groups become 2-row blocks; y must not change by a bit and the pooled tensor
+    # must be exactly the 2x2 max-pool of it (of y2 in mode 4)
+    if h % 2 == 0 and w % (64 if ci == 64 else 32) == 0:
+        for mode in (1, 4):
+            ys, y2s = [], []
+            for pool in (False, True):
+                y = torch.zeros((n, co, h, w), dtype=torch.float16, device="cuda").contiguous(memory_format=torch.channels_last)
+                y2 = torch.zeros_like(y, memory_format=torch.channels_last)
+                pooled = torch.full((n, co, h // 2, w // 2), float("nan"), dtype=torch.float16, device="cuda").contiguous(memory_format=torch.channels_last)
+                common = (vp(x.data_ptr()), None, vp(wt.data_ptr()), vp(b.data_ptr()), vp(ex.data_ptr()), vp(ex2.data_ptr()) if mode == 4 else None,
+                          vp(y.data_ptr()), vp(y2.data_ptr()) if mode == 4 else None)
+                if pool:
+                    rc = L.pp_pw_pool_f16(*common, vp(pooled.data_ptr()), m, hw, w, ci, co, co, mode, 0.01, st)
+                else:
+                    rc = L.pp_pw_f16(*common, m, hw, ci, co, co, mode, 0.01, st)
+                assert rc == 0, (shape, mode, pool, rc)
+                torch.cuda.synchronize()
+                ys.append(y), y2s.append(y2)
+            assert torch.equal(ys[0], ys[1]) and torch.equal(y2s[0], y2s[1])
+            assert torch.equal(pooled, F.max_pool2d(y2s[1] if mode == 4 else ys[1], 2, 2))
 
 
 def test_se_gains_folded_into_the_consumers_keep_the_model_output():
