@@ -42,6 +42,8 @@ struct ConvParams {
     _Float16 *y, *y2;  // y2: second output of mode 4
     const void *zero;  // >= 16 zero bytes: source of every tap that falls outside the image
     int N, H, W, C, K, R, pad, dil, Ho, Wo;
+    float *csum;       // NULL, or per-wave partial channel sums of y (halo kernel): [image][tile][4 pixel waves][K] floats -- the SE
+                       // block's squeeze (models/layers_transposed.py:298-303) without a pass of its own over y
     int ldy;           // elements between consecutive pixels of y (K: packed; larger: y is a channel slice of a wider tensor,
                        // e.g. one half of the backbone's concatenation, models/layers_transposed.py:193-195)
     long M;            // N * Ho * Wo
@@ -78,14 +80,17 @@ __device__ __forceinline__ void lds_dma16_buf(__amdgpu_buffer_rsrc_t rsrc, unsig
 typedef float float2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
-template <int MODE, int PT, int CT, typename PixelOf>
+// sums_row (SUMS): where this wave's partial channel sums go (float[K] of its (image, tile, pixel wave)): the binary16 outputs are
+// summed in fp32 over the wave's pixels -- per lane over its pixel tiles, then over the 16 lanes that hold the same channels.
+template <int MODE, int PT, int CT, bool SUMS = false, typename PixelOf>
 __device__ __forceinline__ void epilogue_body(const float4_t (&acc)[PT][CT], const ConvParams &p, int lane, int nbase,
-                                              PixelOf pixel_of, bool do_store) {
+                                              PixelOf pixel_of, bool do_store, float *sums_row = nullptr) {
     static_assert(CT % 2 == 0, "channel tiles are finished in pairs");
     const int g = lane >> 4, odd = g & 1, cbase = (g & ~1) * 4;
     const float2_t slope2 = float2_t{p.slope, p.slope};
 #pragma unroll
     for (int jp = 0; jp < CT; jp += 2) {
+        float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const int co = nbase + (jp + odd) * 16 + cbase;
         const half8_t bv = *reinterpret_cast<const half8_t *>(p.bias + co);
         float2_t b2[4];
@@ -132,6 +137,22 @@ __device__ __forceinline__ void epilogue_body(const float4_t (&acc)[PT][CT], con
                 }
                 if (do_store) *reinterpret_cast<half8_t *>(p.y + (m * p.ldy + co)) = out;
                 if (MODE == 4 && do_store) *reinterpret_cast<half8_t *>(p.y2 + o) = out2;
+                if (SUMS) {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) csum[e] += (float)out[e];
+                }
+            }
+        }
+        if (SUMS) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+#pragma unroll
+                for (int d = 1; d < 16; d <<= 1) csum[e] += __shfl_xor(csum[e], d);
+            }
+            if ((lane & 15) == 0) {
+                float4 *dst = reinterpret_cast<float4 *>(sums_row + co);
+                dst[0] = make_float4(csum[0], csum[1], csum[2], csum[3]);
+                dst[1] = make_float4(csum[4], csum[5], csum[6], csum[7]);
             }
         }
     }
@@ -218,10 +239,11 @@ __device__ __forceinline__ void epilogue_preloaded(const float4_t (&acc)[PT][CT]
 
 template <int PT, int CT, typename PixelOf>
 __device__ __forceinline__ void epilogue_store(const float4_t (&acc)[PT][CT], const ConvParams &p, int lane, int nbase,
-                                               PixelOf pixel_of, bool do_store) {
+                                               PixelOf pixel_of, bool do_store, float *sums_row = nullptr) {
     if (nbase >= p.K) return;   // a wave whose 64 channels lie past C_out (halo kernel, C_out = 64 mod 128): wave-uniform
     // the residual mode is wave-uniform: three bodies, one scalar branch, no per-element selects
-    if (p.mode == 0) epilogue_body<0, PT, CT>(acc, p, lane, nbase, pixel_of, do_store);
+    if (sums_row) epilogue_body<0, PT, CT, true>(acc, p, lane, nbase, pixel_of, do_store, sums_row);   // mode 0 only (launcher)
+    else if (p.mode == 0) epilogue_body<0, PT, CT>(acc, p, lane, nbase, pixel_of, do_store);
     else if (p.mode == 1) epilogue_body<1, PT, CT>(acc, p, lane, nbase, pixel_of, do_store);
     else if (p.mode == 2) epilogue_body<2, PT, CT>(acc, p, lane, nbase, pixel_of, do_store);
     else if (p.mode == 3) epilogue_body<3, PT, CT>(acc, p, lane, nbase, pixel_of, do_store);
@@ -470,7 +492,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     const int ptiles = p.N * hp.tiles, per_xcd = (ptiles + 7) >> 3;
     const int total_ids = 8 * per_xcd * nct;
     const char *wb = reinterpret_cast<const char *>(p.w);
-    int n_img = 0, ty0 = 0, tx0 = 0, n0 = 0;   // the tile being STAGED (wave-uniform)
+    int n_img = 0, ty0 = 0, tx0 = 0, n0 = 0, t_idx = 0;   // the tile being STAGED (wave-uniform); t_idx: its index inside the image
     const char *xb = nullptr;
     // ---- halo DMA sources.  A piece is 16 halo pixels x 64 B, lane-linear in LDS; the swizzle is applied on the source side.
     // Halo swizzle: bit 5 ^= bit 8 of the byte address inside the halo buffer, i.e. the two 32-B halves of a pixel swap on
@@ -491,6 +513,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
         if (q / nct >= per_xcd || ptile >= ptiles) return false;
         n_img = ptile / hp.tiles;
         const int tile = ptile - n_img * hp.tiles;
+        t_idx = tile;
         ty0 = (tile / hp.tiles_x) * TH;
         tx0 = (tile - (tile / hp.tiles_x) * hp.tiles_x) * TW;
         n0 = ctile * BN;
@@ -603,7 +626,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     for (int z = (int)(blockIdx.x >> 3) * p.stagger / (int)((gridDim.x + 7) >> 3); z > 0; z--) __builtin_amdgcn_s_sleep(127);
     stage_first();
   while (true) {
-    const int c_img = n_img, c_ty0 = ty0, c_tx0 = tx0, c_n0 = n0;   // the tile being COMPUTED
+    const int c_img = n_img, c_ty0 = ty0, c_tx0 = tx0, c_n0 = n0, c_tile = t_idx;   // the tile being COMPUTED
     float4_t acc[PT][CT];
 #pragma unroll
     for (int i = 0; i < PT; i++)
@@ -765,7 +788,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
         const int q = wm * PM + i * 16 + (lane & 15);
         const int qy = q >> LGTW, qx = q & (TW - 1);
         return ((long)c_img * p.H + c_ty0 + qy) * p.W + c_tx0 + qx;
-    }, !(dbg & 8));
+    }, !(dbg & 8), p.csum ? p.csum + (((long)c_img * hp.tiles + c_tile) * WM + wm) * p.K : nullptr);
     stamp(4);            // 4: epilogue (issue)
     if (!has_next) break;
   }
@@ -1136,7 +1159,7 @@ __global__ __launch_bounds__(256) void k_stem7x7(const StemParams p) {
         // ---- epilogue from registers: bias + LeakyReLU, 16-byte stores (epilogue_store)
         ConvParams e;
         e.bias = p.bias, e.extra = nullptr, e.extra2 = nullptr, e.y = p.y, e.y2 = nullptr;
-        e.K = 64, e.ldy = 64, e.mode = 0, e.slope = p.slope;
+        e.K = 64, e.ldy = 64, e.csum = nullptr, e.mode = 0, e.slope = p.slope;
         const int oy = oy0 + wave;
         epilogue_store<4, 4>(acc, e, lane, 0, [&](int i) -> long {
             const int ox = ox0 + 16 * i + pl;
@@ -1317,6 +1340,7 @@ PP_API int pp_conv_own_ex_f16(const void *x, const void *w, const void *bias, co
     p.zero = ds->zero;
     p.N = n; p.H = h; p.W = wd; p.C = c_in; p.K = c_out; p.R = ksize; p.pad = pad; p.dil = dilation; p.Ho = ho; p.Wo = wo;
     p.ldy = c_out;
+    p.csum = nullptr;
     p.M = (long)n * ho * wo;
     p.mode = extra_mode;
     p.slope = slope;
@@ -1339,6 +1363,33 @@ PP_API int pp_conv_own_ex_f16(const void *x, const void *w, const void *bias, co
         case 128: return launch<128>(p, st);
         default: return launch<64>(p, st);
     }
+}
+
+// The 3x3 / pad 1 halo kernel with the SE squeeze of its output on the side: y = act(conv + bias) and sums_ws[image][split][c_out] =
+// partial sums of the binary16 outputs over the pixels of split (tile, pixel wave), fp32; pp_conv_own_sums_splits(h, wd) gives the
+// number of splits per image (0: the shape is not taken).  pp_channel_mean_finish_f16 turns the partials into the mean.
+PP_API int pp_conv_own_sums_splits(int h, int wd) {
+    ConvParams q;
+    q.R = 3, q.pad = 1, q.dil = 1, q.C = 32, q.K = 128, q.H = h, q.W = wd;
+    HaloParams g;
+    return halo_geometry(q, g) ? g.tiles * 4 : 0;
+}
+PP_API int pp_conv_own_sums_f16(const void *x, const void *w, const void *bias, void *y, void *sums_ws, int n, int h, int wd, int c_in,
+                                int c_out, float slope, void *stream) {
+    if (!x || !w || !bias || !y || !sums_ws || n <= 0 || h <= 0 || wd <= 0) return PP_ERR_BAD_ARG;
+    if (!pp_conv_own_supported(c_in, c_out, 3) || !(slope >= 0.f && slope <= 1.f)) return PP_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(y) |
+         reinterpret_cast<uintptr_t>(sums_ws)) & 15)
+        return PP_ERR_BAD_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ConvParams p;
+    p.x = static_cast<const _Float16 *>(x), p.w = static_cast<const _Float16 *>(w), p.bias = static_cast<const _Float16 *>(bias);
+    p.extra = nullptr, p.extra2 = nullptr, p.up = 0, p.y = static_cast<_Float16 *>(y), p.y2 = nullptr, p.zero = nullptr;
+    p.N = n, p.H = h, p.W = wd, p.C = c_in, p.K = c_out, p.R = 3, p.pad = 1, p.dil = 1, p.Ho = h, p.Wo = wd;
+    p.ldy = c_out, p.csum = static_cast<float *>(sums_ws), p.M = (long)n * h * wd, p.mode = 0, p.slope = slope, p.dbg = 0, p.stagger = -1;
+    HaloParams g;
+    if (!halo_geometry(p, g)) return PP_ERR_UNSUPPORTED;
+    return launch_halo(p, g, st);
 }
 
 PP_API int pp_conv_own_f16(const void *x, const void *w, const void *bias, const void *extra, void *y, int n, int h, int wd, int c_in,

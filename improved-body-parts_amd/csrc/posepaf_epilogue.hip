@@ -320,6 +320,16 @@ extern "C" int pp_channel_mean_f16(const void *x, void *partial_ws, void *out, i
     return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
 }
 
+// the second half of pp_channel_mean_f16 alone: partial sums (n, splits, channels) fp32 -> means (n, channels) fp16, summed in
+// split order (deterministic); for producers that emit the partial sums themselves (pp_conv_own_sums_f16)
+extern "C" int pp_channel_mean_finish_f16(const void *partial_ws, void *out, int n, long hw, int channels, int splits, void *stream) {
+    if (!partial_ws || !out || n <= 0 || hw <= 0 || channels <= 0 || splits <= 0) return PP_ERR_BAD_ARG;
+    const int total = n * channels;
+    hipLaunchKernelGGL(k_channel_mean_finish, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const float *>(partial_ws), static_cast<__half *>(out), n, channels, splits, 1.0f / (float)hw);
+    return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
+}
+
 // ------------------------------------------------------------------------------------------------ A0 pre-processing
 // utils/parse_skeletons.py:52-73 + utils/util.py:44-65 for a batch of equally sized BGR uint8 images (scale 1):
 // pad bottom/right to a multiple of `pad_to` with `pad_value`, x / 255 -> float, and emit each image followed by the

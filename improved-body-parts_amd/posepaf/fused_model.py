@@ -39,6 +39,7 @@ TUNE_MIOPEN = os.environ.get("POSEPAF_TUNE_MIOPEN", "0") == "1"   # also time MI
 OWN_VARIANTS = {101: 256, 102: 128, 103: 64, 104: 512}
 PW_VARIANT = 105            # the streaming 1x1 kernel (pp_pw_f16): weights resident in LDS, pixel fragments straight from HBM
 USE_PW = True
+USE_SUM_FUSION = True       # the SE block's channel sums leave the 3x3 kernel that produces the feature map
 USE_POOL_FUSION = True      # the hourglass' 2x2 max-pools leave the 1x1 kernel that produces their input as a second output
 _conv_choice: dict = {}   # shape key -> tile configuration id, or -1 = MIOpen convolution + k_bias_act pass
 _conv_timing: dict = {}   # shape key -> {"miopen": ms, cfg: ms, ...} measured by the autotune (diagnostics)
@@ -566,6 +567,57 @@ class FConv(nn.Module):
                                    h * w, c, k, k, 1 if res is not None else 0, LEAK if self.act else 1.0, _stream(x))
         return y if rc == 0 else None
 
+    def forward_mean(self, x):
+        """-> (y, channel mean of y (n, c_out)) with y = act(conv(x) + bias): the SE squeeze of models/layers_transposed.py:298-303.
+        On the 3x3 halo-tile kernel the per-tile channel sums leave the convolution's epilogue (pp_conv_own_sums_f16) and only a
+        tiny reduction follows; timed once per shape against convolution + the two-pass channel mean."""
+        from . import _lib
+        n, c, h, w = x.shape
+        k = self.weight.shape[0]
+        key = ("mean", n, c, h, w, k, bool(self.act))
+        L = _lib.load() if x.is_cuda else None
+        splits = L.pp_conv_own_sums_splits(h, w) if L is not None else 0
+        ok = (USE_OWN_CONV and USE_SUM_FUSION and x.is_cuda and x.dtype == torch.float16 and self.stride == (1, 1) and splits > 0
+              and tuple(self.weight.shape[2:]) == (3, 3) and self.padding == (1, 1) and self.dilation == (1, 1)
+              and c % 32 == 0 and k % 64 == 0)
+
+        def separate():
+            y = self(x)
+            return y, channel_mean(y)
+
+        def fused():
+            xx = _cl(x)
+            if not self.weight.is_contiguous(memory_format=torch.channels_last):
+                self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
+            y = torch.empty((n, k, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            ws = torch.empty((n, splits, k), dtype=torch.float32, device=x.device)
+            mean = torch.empty((n, k), dtype=x.dtype, device=x.device)
+            rc = L.pp_conv_own_sums_f16(_ptr(xx), _ptr(self.weight), _ptr(self.bias), _ptr(y), _ptr(ws), n, h, w, c, k,
+                                        LEAK if self.act else 1.0, _stream(x))
+            if rc != 0:
+                return None
+            _lib.check(L.pp_channel_mean_finish_f16(_ptr(ws), _ptr(mean), n, h * w, k, splits, _stream(x)))
+            return y, mean
+
+        choice = _conv_choice.get(key) if ok else 0
+        if choice is None:
+            if torch.cuda.is_current_stream_capturing():
+                return separate()
+            separate()
+            if fused() is None:
+                choice = 0
+            else:
+                t_sep, t_fused = _timed(separate), _timed(fused)
+                _conv_timing[key] = {"separate": t_sep, "fused": t_fused}
+                choice = 1 if t_fused < t_sep else 0
+            _conv_choice[key] = choice
+            _note(key, choice)
+        if choice:
+            out = fused()
+            if out is not None:
+                return out
+        return separate()
+
     def forward_pool(self, x, res=None):
         """-> (y, maxpool2(y)) with y = act(conv(x) + bias (+ res)).  For a 1x1 convolution the pooled tensor can leave the
         streaming kernel as one more output (pp_pw_pool_f16) instead of a pass of its own; timed once per shape against
@@ -689,6 +741,7 @@ class FHead(FConv):
         self.wpad = nn.Parameter(wpad, requires_grad=False)
         self.bpad = nn.Parameter(bpad, requires_grad=False)
         self.k_real = k
+        self.last_padded = None
 
     def forward(self, x, res=None, post=None):
         from . import _lib
@@ -706,7 +759,9 @@ class FHead(FConv):
                                        None, None, _ptr(y), None, n * h * w, h * w, c, kp, kp, 0, LEAK if self.act else 1.0,
                                        _stream(xx))
             if rc == 0:
+                self.last_padded = y           # the 64-channel tensor behind the view (channels 50..63 are exact zeros)
                 return y[:, : self.k_real]
+        self.last_padded = None
         return super().forward(xs.materialize() if xs is not None else x, res, post)
 
 
@@ -773,8 +828,9 @@ class FSE(nn.Module):
         super().__init__()
         self.fc1, self.fc2 = se.fc[0], se.fc[2]
 
-    def forward(self, x, fold: bool = False):
-        y = channel_mean(x)
+    def forward(self, x, fold: bool = False, mean=None):
+        """mean: the channel mean of x when its producer already made it (FConv.forward_mean)"""
+        y = channel_mean(x) if mean is None else mean
         y = torch.sigmoid(self.fc2(F.leaky_relu(self.fc1(y), 0.01)))
         if fold and x.is_cuda and x.dtype == torch.float16 and USE_PW and USE_OWN_CONV:
             return Scaled(x, y)            # the consumers (1x1 head / merge convolutions) multiply while they read
@@ -787,7 +843,8 @@ class FFeature(nn.Module):
         self.c1, self.c2, self.se = _fconv_from_block(seq[0]), _fconv_from_block(seq[1]), FSE(seq[2])
 
     def forward(self, x, fold: bool = False):
-        return self.se(self.c2(self.c1(x)), fold)
+        y, mean = self.c2.forward_mean(self.c1(x))
+        return self.se(y, fold, mean)
 
 
 class FusedIMHN(nn.Module):
@@ -810,6 +867,11 @@ class FusedIMHN(nn.Module):
         for mf, mp in zip(self.mfeat, self.mpred):
             for f, q in zip(mf, mp):
                 f.bias = nn.Parameter(f.bias + q.bias, requires_grad=False)
+                # the heads hand over a 64-channel tensor (50 + 14 exact zeros): the prediction-merge convolution reads it
+                # as it is, through a weight whose input channels 50..63 are zero (no copy of the [:, :50] view)
+                wq = torch.zeros((q.weight.shape[0], 64, 1, 1), dtype=q.weight.dtype)
+                wq[:, : q.weight.shape[1]] = q.weight.detach()
+                q.w_in64 = nn.Parameter(wq, requires_grad=False)
 
     @classmethod
     def from_network(cls, net):
@@ -840,8 +902,16 @@ class FusedIMHN(nn.Module):
             if last:
                 return seen if stage_preds else preds[0]
             # cache_s = merge_feat(feat_s) + merge_pred(pred_s); x + cache_0 leaves the scale-0 convolution as a second output
-            c0, x, x_pooled = self.mfeat[t][0].forward_dual(feats[0], self.mpred[t][0].conv_only(preds[0]), x, want_pool=True)
-            caches = [c0] + [self.mfeat[t][s](feats[s], self.mpred[t][s].conv_only(preds[s])) for s in scales if s > 0]
+            mp = [self._merge_pred(t, s, preds[s]) for s in scales]
+            c0, x, x_pooled = self.mfeat[t][0].forward_dual(feats[0], mp[0], x, want_pool=True)
+            caches = [c0] + [self.mfeat[t][s](feats[s], mp[s]) for s in scales if s > 0]
+
+    def _merge_pred(self, t, s, pred):
+        """merge_preds[t][s](pred) without its bias (summed into the feature-merge convolution's)"""
+        q, padded = self.mpred[t][s], self.head[t][s].last_padded
+        if padded is not None and padded.shape[1] == 64:
+            return F.conv2d(padded, q.w_in64)
+        return q.conv_only(pred)
 
 
 class GraphedForward:

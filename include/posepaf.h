@@ -156,6 +156,14 @@ PP_API int pp_add3_f16(const void *a, const void *b, const void *c, void *y, lon
  * activation x (n, hw, channels), fp32 accumulation.  partial_ws: DEVICE float[n][splits][channels] scratch; splits = number of
  * workgroups per image (pick n*splits >= ~1024).  channels % 8 == 0, channels <= 2048. */
 PP_API int pp_channel_mean_f16(const void *x, void *partial_ws, void *out, int n, long hw, int channels, int splits, void *stream);
+/* The SE squeeze without a pass of its own (round 3): the 3x3 / pad 1 halo-tile kernel writes y = act(conv + bias) AND, per image,
+ * per-split partial sums of its binary16 outputs: sums_ws DEVICE float[n][splits][c_out], splits = pp_conv_own_sums_splits(h, w)
+ * (0: the shape is not taken by that kernel); pp_channel_mean_finish_f16 adds the partials in split order and writes the fp16 mean
+ * (= pp_channel_mean_f16's second kernel). */
+PP_API int pp_conv_own_sums_splits(int h, int w);
+PP_API int pp_conv_own_sums_f16(const void *x, const void *w, const void *bias, void *y, void *sums_ws, int n, int h, int wd, int c_in,
+                                int c_out, float slope, void *stream);
+PP_API int pp_channel_mean_finish_f16(const void *partial_ws, void *out, int n, long hw, int channels, int splits, void *stream);
 /* SE excitation: y[n][p][c] = x[n][p][c] * scale[n][c] on NHWC fp16 (x: (n, hw, channels), scale: fp16 (n, channels)); y may be x. */
 PP_API int pp_channel_scale_f16(const void *x, const void *scale, void *y, int n, long hw, int channels, void *stream);
 

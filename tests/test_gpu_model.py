@@ -189,6 +189,37 @@ def test_streaming_pointwise_convolution_matches_torch(shape):
             assert torch.equal(pooled, F.max_pool2d(y2s[1] if mode == 4 else ys[1], 2, 2))
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 128, 32, 32), (1, 256, 256, 16, 64), (3, 96, 192, 16, 128)])
+def test_halo_kernel_emits_the_channel_sums_of_its_output(shape):
+    """pp_conv_own_sums_f16 + pp_channel_mean_finish_f16: y bit-equal to the plain halo-kernel launch, and the mean equal to the
+    fp32 mean of that fp16 tensor within fp32 summation-order noise (the SE squeeze, models/layers_transposed.py:298-303)."""
+    import ctypes as C
+    from posepaf import _lib
+    L = _lib.load()
+    n, ci, co, h, w = shape
+    g = torch.Generator(device="cpu").manual_seed(53)
+    x = torch.randn(n, ci, h, w, generator=g).cuda().half().contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(co, ci, 3, 3, generator=g) / (ci * 9) ** 0.5).cuda().half().contiguous(memory_format=torch.channels_last)
+    b = torch.randn(co, generator=g).cuda().half()
+    vp = C.c_void_p
+    st = vp(torch.cuda.current_stream().cuda_stream)
+    splits = L.pp_conv_own_sums_splits(h, w)
+    assert splits > 0
+    y0 = torch.empty((n, co, h, w), dtype=torch.float16, device="cuda").contiguous(memory_format=torch.channels_last)
+    assert L.pp_conv_own_f16(vp(x.data_ptr()), vp(wt.data_ptr()), vp(b.data_ptr()), None, vp(y0.data_ptr()), n, h, w, ci, co, 3, 1, 1, 0,
+                             0.01, 512, st) == 0
+    y1 = torch.empty_like(y0, memory_format=torch.channels_last)
+    ws = torch.full((n, splits, co), float("nan"), dtype=torch.float32, device="cuda")
+    mean = torch.empty((n, co), dtype=torch.float16, device="cuda")
+    assert L.pp_conv_own_sums_f16(vp(x.data_ptr()), vp(wt.data_ptr()), vp(b.data_ptr()), vp(y1.data_ptr()), vp(ws.data_ptr()), n, h, w, ci,
+                                  co, 0.01, st) == 0
+    assert L.pp_channel_mean_finish_f16(vp(ws.data_ptr()), vp(mean.data_ptr()), n, h * w, co, splits, st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1) and torch.isfinite(ws).all()
+    want = y1.float().mean(dim=(2, 3))
+    assert (mean.float() - want).abs().max().item() <= 1e-3 * max(1.0, want.abs().max().item())
+
+
 def test_se_gains_folded_into_the_consumers_keep_the_model_output():
     """FusedIMHN with the SE gains folded into the head / merge convolutions' input read (Scaled + pp_pw_f16) against the same
     model with the separate x * s pass (USE_PW = False): same arithmetic up to the accumulation order of the 1x1 kernels."""
