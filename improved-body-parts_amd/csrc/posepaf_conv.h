@@ -4,6 +4,8 @@ struct PPConvArgs {
     const void *x, *w, *bias, *extra;  // NHWC fp16, (K, R, S, C) fp16, fp16[K], optional NHWC (N, Ho, Wo, K) fp16
     void *y;                           // (N, Ho, Wo, K) fp16
     int N, H, W, C, K, R, S, pad, dil;
+    int ldx, ldy;                      // elements between consecutive pixels of x / y (C / K: packed; larger: a channel slice of a wider
+                                       // NHWC tensor -- the backbone's concatenation, models/layers_transposed.py:193-195)
     int extra_mode;                    // 0 none, 1 added before the activation (residual), 2 after it (post)
     float slope;                       // LeakyReLU slope; 1.0 = no activation
     void *stream;

@@ -136,14 +136,16 @@ int run_part(const PPConvArgs &a, int n0, int n, bool launch) {
     using idx = ck::index_t;
     const idx G = 1, N = n, H = a.H, W = a.W, C = a.C, K = a.K, R = a.R, Sx = a.S;
     const idx Ho = H + 2 * a.pad - a.dil * (R - 1), Wo = W + 2 * a.pad - a.dil * (Sx - 1);
-    const size_t in_off = (size_t)n0 * H * W * C * sizeof(F16), out_off = (size_t)n0 * Ho * Wo * K * sizeof(F16);
+    const idx LX = a.ldx, LY = a.ldy;   // pixel strides of x / y: C / K when packed, larger for a channel slice of a wider tensor
+    const size_t in_off = (size_t)n0 * H * W * LX * sizeof(F16), out_off = (size_t)n0 * Ho * Wo * K * sizeof(F16);
     const void *x = static_cast<const char *>(a.x) + in_off;
     const void *extra = a.extra ? static_cast<const char *>(a.extra) + out_off : nullptr;
-    void *y = static_cast<char *>(a.y) + out_off;
-    // lengths in (G, N, C|K, spatial...) order; strides describe the packed NHWGC / GKYXC / NHWGK tensors (G = 1)
-    const std::array<idx, 5> a_len{G, N, C, H, W}, a_str{C, H * W * C, 1, W * C, C};
+    void *y = static_cast<char *>(a.y) + (size_t)n0 * Ho * Wo * LY * sizeof(F16);
+    // lengths in (G, N, C|K, spatial...) order; strides of the NHWGC / GKYXC / NHWGK tensors (G = 1); x_str: the packed extra
+    const std::array<idx, 5> a_len{G, N, C, H, W}, a_str{C, H * W * LX, 1, W * LX, LX};
     const std::array<idx, 5> b_len{G, K, C, R, Sx}, b_str{K * R * Sx * C, R * Sx * C, 1, Sx * C, C};
-    const std::array<idx, 5> e_len{G, N, K, Ho, Wo}, e_str{K, Ho * Wo * K, 1, Wo * K, K};
+    const std::array<idx, 5> e_len{G, N, K, Ho, Wo}, e_str{K, Ho * Wo * LY, 1, Wo * LY, LY};
+    const std::array<idx, 5> x_str{K, Ho * Wo * K, 1, Wo * K, K};
     const std::array<idx, 5> bias_str{K, 0, 1, 0, 0};
     const std::array<idx, 2> strides{1, 1}, dil{a.dil, a.dil}, pads{a.pad, a.pad};
     const StreamConfig cfg{static_cast<hipStream_t>(a.stream), false};
@@ -158,7 +160,7 @@ int run_part(const PPConvArgs &a, int n0, int n, bool launch) {
         ConvBiasAdd op;
         auto arg = op.MakeArgument(x, a.w, std::array<const void *, 2>{a.bias, extra}, y, a_len, a_str, b_len, b_str,
                                    std::array<std::array<idx, 5>, 2>{e_len, e_len},
-                                   std::array<std::array<idx, 5>, 2>{bias_str, e_str}, e_len, e_str, strides, dil, pads, pads,
+                                   std::array<std::array<idx, 5>, 2>{bias_str, x_str}, e_len, e_str, strides, dil, pads, pads,
                                    PassThrough{}, PassThrough{}, BiasAddLeaky{a.slope, a.extra_mode == 1});
         if (!op.IsSupportedArgument(arg)) return -1;
         if (launch) op.MakeInvoker().Run(arg, cfg);

@@ -40,6 +40,7 @@ OWN_VARIANTS = {101: 256, 102: 128, 103: 64, 104: 512}
 PW_VARIANT = 105            # the streaming 1x1 kernel (pp_pw_f16): weights resident in LDS, pixel fragments straight from HBM
 USE_PW = True
 USE_SUM_FUSION = True       # the SE block's channel sums leave the 3x3 kernel that produces the feature map
+USE_SLICE_OUTPUT = True     # the backbone's concatenation is written in place by its two producers
 USE_POOL_FUSION = True      # the hourglass' 2x2 max-pools leave the 1x1 kernel that produces their input as a second output
 _conv_choice: dict = {}   # shape key -> tile configuration id, or -1 = MIOpen convolution + k_bias_act pass
 _conv_timing: dict = {}   # shape key -> {"miopen": ms, cfg: ms, ...} measured by the autotune (diagnostics)
@@ -157,6 +158,15 @@ def load_table(path: str | None = None, force: bool = False) -> int:
 
 def _cl(t):
     return t if t.is_contiguous(memory_format=torch.channels_last) else t.contiguous(memory_format=torch.channels_last)
+
+
+def _slice_ld(t):
+    """pixel stride (elements) of t when it is channels-last OR a channel slice of a channels-last tensor, else None"""
+    n, c, h, w = t.shape
+    sn, sc, sh, sw = t.stride()
+    if sc == 1 and sw >= c and sh == w * sw and (n == 1 or sn == h * w * sw) and sw % 8 == 0:
+        return sw
+    return None
 
 
 def _ptr(t):
@@ -325,6 +335,8 @@ class FConv(nn.Module):
     def _fused_launch(self, cfg, x, extra, mode, y):
         from . import _lib
         n, c, h, w = x.shape
+        if cfg >= 100 and (x.stride(3) != c or (cfg != PW_VARIANT and y.stride(3) != self.weight.shape[0])):
+            return -6   # the hand-written kernels read packed inputs; only the streaming 1x1 kernel writes a channel slice
         if cfg == PW_VARIANT:
             if self.weight.shape[2] != 1 or self.padding[0] != 0:
                 return -6
@@ -335,14 +347,15 @@ class FConv(nn.Module):
             return _lib.load().pp_conv_own_f16(_ptr(x), _ptr(self.weight), _ptr(self.bias), _ptr(extra), _ptr(y), n, h, w, c,
                                                self.weight.shape[0], self.weight.shape[2], self.padding[0], self.dilation[0], mode,
                                                LEAK if self.act else 1.0, OWN_VARIANTS[cfg], _stream(x))
-        return _lib.load().pp_conv_f16(_ptr(x), _ptr(self.weight), _ptr(self.bias), _ptr(extra), _ptr(y), n, h, w, c,
-                                       self.weight.shape[0], self.weight.shape[2], self.padding[0], self.dilation[0], mode,
-                                       LEAK if self.act else 1.0, cfg, _stream(x))
+        return _lib.load().pp_conv_ld_f16(_ptr(x), _ptr(self.weight), _ptr(self.bias), _ptr(extra), _ptr(y), n, h, w, c,
+                                          self.weight.shape[0], self.weight.shape[2], self.padding[0], self.dilation[0], mode,
+                                          LEAK if self.act else 1.0, cfg, x.stride(3), y.stride(3), _stream(x))
 
-    def _fused(self, x, res, post):
-        """-> y, or None when this shape runs faster (or only) on the MIOpen + epilogue path."""
+    def _fused(self, x, res, post, out=None):
+        """-> y, or None when this shape runs faster (or only) on the MIOpen + epilogue path.  x may be a channel slice of a wider
+        channels-last tensor and `out` (optional) another: the kernels that take pixel strides read / write them in place."""
         from . import _lib
-        x = _cl(x)
+        x = x if _slice_ld(x) is not None else _cl(x)
         extra = res if res is not None else post
         extra = _cl(extra) if extra is not None else None
         mode = 1 if res is not None else (2 if post is not None else 0)
@@ -353,9 +366,12 @@ class FConv(nn.Module):
         ho = h + 2 * self.padding[0] - self.dilation[0] * (r - 1)
         wo = w + 2 * self.padding[0] - self.dilation[0] * (r - 1)
         key = (n, c, h, w, k, r, self.padding[0], self.dilation[0], mode, bool(self.act))
+        sliced = x.stride(3) != c or (out is not None and out.stride(3) != k)
+        if sliced:   # its own tuning entry: only the kernels that take pixel strides compete
+            key = key + ("slice", x.stride(3), out.stride(3) if out is not None else k)
         choice = _conv_choice.get(key)
         _conv_calls[key] = _conv_calls.get(key, 0) + 1
-        y = torch.empty((n, k, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        y = out if out is not None else torch.empty((n, k, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         if choice is None:
             if torch.cuda.is_current_stream_capturing():
                 return None  # cannot time inside a capture; shapes are tuned by the eager warm-up pass
@@ -665,8 +681,15 @@ class FConv(nn.Module):
                 return out
         return separate()
 
-    def forward(self, x, res=None, post=None):
-        """act(conv(x) + bias (+ res)) (+ post)"""
+    def forward(self, x, res=None, post=None, out=None):
+        """act(conv(x) + bias (+ res)) (+ post); out: optional destination, e.g. a channel slice of a wider channels-last tensor"""
+        if out is not None:
+            if not isinstance(x, Scaled) and self._fused_eligible(x, res, post) and _slice_ld(out) is not None:
+                y = self._fused(x, res, post, out)
+                if y is not None:
+                    return y
+            out.copy_(self.forward(x if isinstance(x, Scaled) or _slice_ld(x) == x.shape[1] else x.contiguous(memory_format=torch.channels_last), res, post))
+            return out
         if isinstance(x, Scaled):
             y = self.forward_scaled(x, res) if post is None else None
             if y is not None:
@@ -781,9 +804,9 @@ class FResidual(nn.Module):
         if self.skip is not None:  # conv3 + b3 + convs + bs: one bias vector, the skip conv runs bias-free
             self.c3.bias = nn.Parameter(self.c3.bias + self.skip.bias, requires_grad=False)
 
-    def forward(self, x):
+    def forward(self, x, out=None):
         res = self.skip.conv_only(x) if self.skip is not None else x
-        return self.c3(self.c2(self.c1(x)), res)
+        return self.c3(self.c2(self.c1(x)), res, out=out)
 
     def forward_pool(self, x):
         """-> (block output, its 2x2 max-pool): the pooled tensor leaves the block's last 1x1 convolution as a second output"""
@@ -882,11 +905,25 @@ class FusedIMHN(nn.Module):
         seen = []
         x = imgs.permute(0, 3, 1, 2)  # NHWC storage viewed as NCHW == channels_last: no copy
         x = self.stem(x)
-        x = self.res2(self.res1.forward_pool(x)[1])
-        d = x
-        for m in self.dil:
-            d = m(d)
-        x = torch.cat([x, d], dim=1)
+        # torch.cat([x, dilation(x)]) of Backbone.forward (models/layers_transposed.py:193-195) without the copy: both halves are
+        # written in place -- res2's last 1x1 into [:, :C], the last dilated convolution into [:, C:] -- and the dilated chain reads
+        # the first half where it lies (kernels with pixel strides: pp_pw_f16 / pp_conv_ld_f16)
+        pooled = self.res1.forward_pool(x)[1]
+        if USE_SLICE_OUTPUT and pooled.is_cuda and pooled.dtype == torch.float16:
+            c2 = self.res2.c3.weight.shape[0]
+            cd = self.dil[-1].weight.shape[0]
+            n, _, h, w = pooled.shape
+            buf = torch.empty((n, c2 + cd, h, w), dtype=pooled.dtype, device=pooled.device, memory_format=torch.channels_last)
+            d = self.res2(pooled, out=buf[:, :c2])
+            for i, m in enumerate(self.dil):
+                d = m(d, out=buf[:, c2:] if i == len(self.dil) - 1 else None)
+            x = buf
+        else:
+            x = self.res2(pooled)
+            d = x
+            for m in self.dil:
+                d = m(d)
+            x = torch.cat([x, d], dim=1)
         caches, x_pooled = None, None
         for t in range(self.S):
             last = t == self.S - 1

@@ -193,6 +193,13 @@ PP_API int pp_conv_f16(const void *x, const void *w, const void *bias, const voi
                        int c_in, int c_out, int ksize, int pad, int dilation, int extra_mode, float slope, int config,
                        void *stream);
 
+/* pp_conv_f16 with explicit pixel strides (elements, multiples of 8): x and / or y may be a channel slice of a wider NHWC tensor
+ * (ldx >= c_in, ldy >= c_out) -- the two halves of the backbone's concatenation (models/layers_transposed.py:193-195) are
+ * written in place by their producers and read in place by the dilated chain. */
+PP_API int pp_conv_ld_f16(const void *x, const void *w, const void *bias, const void *extra, void *y, int n, int h, int wd,
+                          int c_in, int c_out, int ksize, int pad, int dilation, int extra_mode, float slope, int config, int ldx,
+                          int ldy, void *stream);
+
 /* A1 forward: the same fused convolution as pp_conv_f16 -- identical arguments and semantics -- as a HAND-WRITTEN implicit-GEMM
  * kernel (csrc/posepaf_conv_own.hip: 256-pixel x bn-channel workgroup tiles, LDS-DMA staging, v_mfma_f32_16x16x32_f16, epilogue
  * from registers; no composable_kernel).  Needs c_in % 32 == 0 and c_out % 64 == 0 (pp_conv_own_supported).  bn = output

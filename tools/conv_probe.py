@@ -23,9 +23,9 @@ torch.cuda.synchronize()
 rows = []
 up2 = {k_: v for k_, v in fm._conv_timing.items() if k_[0] == "up2"}   # upsample -> 3x3 -> add(s): separate launches vs one (forward_up2)
 for key, times in fm._conv_timing.items():
-    if key[0] in ("up2", "dual"):
+    if key[0] in ("up2", "dual", "pool", "mean"):
         continue
-    n, c, h, w, k, r, pad, dil, mode, act = key
+    n, c, h, w, k, r, pad, dil, mode, act = key[:10]   # (+ ("slice", ldx, ldy) for the in-place halves of the concatenation)
     calls = fm._conv_calls.get(key, 0)
     best = fm._conv_choice[key]
     t = times["miopen"] if best < 0 else times[best]
@@ -36,7 +36,7 @@ rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
 print(f"{'c_in':>5} {'c_out':>5} {'hxw':>9} k pad dil mode act | calls cfg   best_ms  miopen_ms  TFLOP/s    GB/s  share")
 for tt, key, calls, best, t, tm, tf, gb in rows:
-    n, c, h, w, k, r, pad, dil, mode, act = key
+    n, c, h, w, k, r, pad, dil, mode, act = key[:10]
     print(f"{c:5d} {k:5d} {h:4d}x{w:<4d} {r} {pad:3d} {dil:3d} {mode:4d} {int(act):3d} | {calls:5d} {best:3d} {t:9.3f} {tm:10.3f} {tf:8.0f} {gb:7.0f} {100 * tt / tot:5.1f}%")
 print(f"sum over tuned shapes: {tot:.2f} ms per forward")
 print("all configurations, ms (top 8 shapes):")
