@@ -594,16 +594,26 @@ def test_two_output_convolution_matches_convolution_plus_add():
     res = torch.randn(2, 256, 32, 32, device="cuda").half().contiguous(memory_format=torch.channels_last)
     other = torch.randn(2, 256, 32, 32, device="cuda").half().contiguous(memory_format=torch.channels_last)
     ref = f(x, res)
-    key = ("dual", 2, 128, 32, 32, 256, 1, 0, 1, False)
-    for choice in (0, 256, 128):
+    key = ("dual", 2, 128, 32, 32, 256, 1, 0, 1, False, False, False)      # (..., SE gains folded, pooled third output)
+    tol = 2e-3 * max(1.0, ref.float().abs().max().item())
+    for choice in (0, 256, 128, fm.PW_VARIANT):
         fm._conv_choice[key] = choice
         y, y2 = f.forward_dual(x, res, other)
-        tol = 2e-3 * max(1.0, ref.float().abs().max().item())
         assert (y.float() - ref.float()).abs().max().item() <= tol, choice
         assert torch.equal(y2, y + other), choice
     fm._conv_choice.pop(key)
     y, y2 = f.forward_dual(x, res, other)
     assert key in fm._conv_choice and torch.equal(y2, y + other)
+    # the streaming 1x1 kernel's extras: the SE gains folded into the input read, and the 2x2 max-pool of y2 as a third output
+    import torch.nn.functional as F
+    gains = (0.3 + torch.rand(2, 128, device="cuda")).half()
+    ref_s = f(fm.channel_scale(x, gains), res)
+    keyp = ("dual", 2, 128, 32, 32, 256, 1, 0, 1, False, True, True)
+    for choice in (0, fm.PW_VARIANT):
+        fm._conv_choice[keyp] = choice
+        y, y2, pooled = f.forward_dual(fm.Scaled(x, gains), res, other, want_pool=True)
+        assert (y.float() - ref_s.float()).abs().max().item() <= tol, choice
+        assert torch.equal(y2, y + other) and torch.equal(pooled, F.max_pool2d(y2, 2, 2)), choice
 
 
 def test_fused_model_upsample_convolution_paths_agree():
