@@ -56,7 +56,8 @@ __device__ const float d_cubic4[4][4] = {{-0.06591796875f, 0.42626953125f, 0.749
 // Diagnostic phase stamps (shader clock) written per workgroup when a stamp buffer is registered with
 // pp_debug_set_stamps(); a null pointer (the default) costs one scalar branch per phase.
 __device__ long long *d_stamps = nullptr;
-__device__ int d_stamp_realtime = 0;   // 1: the chip-wide 100 MHz counter (timelines across CUs) instead of the shader clock
+__device__ int d_stamp_realtime = 0;
+__device__ int d_sp_max_pairs = 128;   // K_B: limbs with at most this many candidate pairs spread a pair's SAMPLES over lanes (<= 512)   // 1: the chip-wide 100 MHz counter (timelines across CUs) instead of the shader clock
 __device__ __forceinline__ void stamp(long long *buf, int wg, int slot) {
     if (buf && threadIdx.x == 0) buf[(size_t)wg * 8 + slot] = d_stamp_realtime ? (long long)wall_clock64() : (long long)clock64();
 }
@@ -958,7 +959,7 @@ __device__ int connect_limb(const Sampler &smp, const LimbLds &L, int nA, int nB
     // and the running sum is then formed by every lane of the group in the reference's order (s0 + s1 + ...; lanes past the
     // pair's step count contribute +0.0f, the identity: a running sum that starts at +0.0f is never -0.0f).  Same values, same
     // additions in the same order, a dependent chain five times shorter.
-    const bool sample_parallel = npairs <= NT / 2;
+    const bool sample_parallel = npairs <= d_sp_max_pairs;
     if (sample_parallel) {
         constexpr int G1 = 8, PP1 = NT / G1;     // lanes per pair / pairs per round, first instalment
         constexpr int G2 = 16, PP2 = NT / G2;    // second instalment: samples kFirst .. 19 (twelve of the sixteen lanes work)
@@ -3521,6 +3522,12 @@ hipError_t set_stamp_buffer(long long *buf) {
 
 hipError_t init_kernel_attributes() {
     const int lim = (int)kMaxDynLds;
+    if (const char *e = getenv("POSEPAF_KB_SP_PAIRS")) {   // A/B measurements of the sample-parallel threshold
+        int v = atoi(e);
+        v = v < 0 ? 0 : (v > 512 ? 512 : v);
+        hipError_t err = hipMemcpyToSymbol(HIP_SYMBOL(d_sp_max_pairs), &v, sizeof(v));
+        if (err != hipSuccess) return err;
+    }
     const void *fns[] = {reinterpret_cast<const void *>(&k_heat_peaks<__half>),
                          reinterpret_cast<const void *>(&k_heat_peaks<float>),
                          reinterpret_cast<const void *>(&k_limb_connect<__half, 256>),
