@@ -516,15 +516,19 @@ class GpuEngine:
             if not a.plain_model:
                 from posepaf import fused_model
                 ch = fused_model.conv_choices()
-                up2 = {k: v for k, v in ch.items() if k[0] == "up2"}     # upsample -> 3x3 -> add(s): 1 = one launch of the halo kernel
-                dual = {k: v for k, v in ch.items() if k[0] == "dual"}   # convolution with a second output y + other: 0 = separate add
-                ch = {k: v for k, v in ch.items() if k[0] not in ("up2", "dual") and k[0] == 2 * B}
+                # (the table may hold other geometries -- multi-scale runs, other batch sizes: count this step's 2 B samples only)
+                up2 = {k: v for k, v in ch.items() if k[0] == "up2" and k[1] == 2 * B}     # upsample -> 3x3 -> add(s): 1 = one launch of the halo kernel
+                dual = {k: v for k, v in ch.items() if k[0] == "dual" and k[1] == 2 * B}   # convolution with a second output y + other: 0 = separate add
+                side = {k: v for k, v in ch.items() if k[0] in ("pool", "mean") and k[1] == 2 * B}   # pooled output / SE channel sums from the producer's epilogue
+                ch = {k: v for k, v in ch.items() if isinstance(k[0], int) and k[0] == 2 * B}
                 out["conv_layers"] = {"shapes_own_kernel": sum(1 for v in ch.values() if v >= 100),
                                       "shapes_ck_template_kernel": sum(1 for v in ch.values() if 0 <= v < 100),
                                       "shapes_miopen_plus_epilogue": sum(1 for v in ch.values() if v < 0),
                                       "upsample_conv_add_sites_fused": sum(1 for v in up2.values() if v),
                                       "upsample_conv_add_sites_separate": sum(1 for v in up2.values() if not v),
                                       "two_output_conv_sites_fused": sum(1 for v in dual.values() if v),
+                                      "pooled_or_channel_sum_outputs_fused": sum(1 for v in side.values() if v),
+                                      "shapes_streaming_1x1_kernel": sum(1 for v in ch.values() if v == 105),
                                       "choice_table_hash": fused_model.table_hash(),
                                       "choice_table": "loaded from " + fused_model.default_table_path() if self.table_loaded
                                       else "tuned in this run's warm-up"}

@@ -449,6 +449,8 @@ struct HaloParams {
     int TW, TH, lgTW;       // tile width (power of two, <= 128), height = 512 / TW
     int tiles_x, tiles;     // tiles per image row / per image
     int HWp, nhalo, npieces;  // halo row length TW + 2, halo pixels, 16-pixel DMA pieces (last one padded)
+    int gimg, hrows;          // images per tile and halo rows per image: 1 / TH + 2, or -- maps lower than a tile (16 x 16) -- TH / H
+                              // WHOLE images stacked in one tile, each with its own H + 2 halo rows
 };
 
 // DIAGNOSTIC (MASK bit 1024): shader clock / 100 MHz reference clock stamps around the main loop of each workgroup's first tile
@@ -457,7 +459,7 @@ __device__ unsigned long long g_conv_clk[8 * 512];
 template <int BN, int MASK, int LGTW>
 __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, const HaloParams hp) {
     // The tile geometry is a template parameter: every fragment address is then "lane register + immediate" (see R[][] below).
-    constexpr int TW = 1 << LGTW, HWp = TW + 2, TH = TP / TW, NHALO = (TH + 2) * HWp;
+    constexpr int TW = 1 << LGTW, HWp = TW + 2, TH = TP / TW;
     constexpr int dbg = MASK;  // ablation switches are COMPILE-TIME (a runtime switch costs a branch per guarded instruction); 0 in production
     constexpr int WN = BN / 64;          // 2
     constexpr int WM = 8 / WN;           // 4
@@ -489,7 +491,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     // of the non-persistent form).
     const int nct = (p.K + BN - 1) / BN;   // C_out = 64 mod 128: the upper half of the last tile has no channels (its weight
                                            // rows read as zeros through the buffer bounds, its epilogue is skipped)
-    const int ptiles = p.N * hp.tiles, per_xcd = (ptiles + 7) >> 3;
+    const int ptiles = (p.N / hp.gimg) * hp.tiles, per_xcd = (ptiles + 7) >> 3;
     const int total_ids = 8 * per_xcd * nct;
     const char *wb = reinterpret_cast<const char *>(p.w);
     int n_img = 0, ty0 = 0, tx0 = 0, n0 = 0, t_idx = 0;   // the tile being STAGED (wave-uniform); t_idx: its index inside the image
@@ -511,8 +513,8 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
         const int xcd = id & 7, q = id >> 3;
         const int ptile = xcd * per_xcd + q / nct, ctile = q - (q / nct) * nct;
         if (q / nct >= per_xcd || ptile >= ptiles) return false;
-        n_img = ptile / hp.tiles;
-        const int tile = ptile - n_img * hp.tiles;
+        n_img = (ptile / hp.tiles) * hp.gimg;   // the tile's (first) image
+        const int tile = ptile - (ptile / hp.tiles) * hp.tiles;
         t_idx = tile;
         ty0 = (tile / hp.tiles_x) * TH;
         tx0 = (tile - (tile / hp.tiles_x) * hp.tiles_x) * TW;
@@ -528,9 +530,11 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
             const int logical = phys ^ (((phys >> 8) & 1) << 5);
             const int hpix = logical >> 6, chunk = (logical >> 4) & 3;
             const int hy = hpix / HWp, hx = hpix - hy * HWp;
-            const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
-            const bool ok = hpix < NHALO && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            hsrc[t] = ok ? (((iy >> p.up) * sw_ + (ix >> p.up)) * p.C * 2 + chunk * 16) : (int)0x80000000;   // outside num_records: zeros
+            const int gi = hy / hp.hrows;                              // image of the tile this halo row belongs to (0 unless stacked)
+            const int iy = ty0 - 1 + (hy - gi * hp.hrows), ix = tx0 - 1 + hx;
+            const bool ok = hpix < hp.nhalo && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            hsrc[t] = ok ? (((gi * (p.H >> p.up) + (iy >> p.up)) * sw_ + (ix >> p.up)) * p.C * 2 + chunk * 16)
+                         : (int)0x80000000;   // outside num_records: zeros
         }
         const int b = ln * 16;
         const int bs = b ^ (((b >> 9) & 1) << 5);
@@ -541,7 +545,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
         const unsigned long long aw = reinterpret_cast<unsigned long long>(wb) + (unsigned long long)((long)(n0 + wave * 16) * (9L * p.C * 2));
         bx_lo = __builtin_amdgcn_readfirstlane((int)(unsigned)ax), bx_hi = __builtin_amdgcn_readfirstlane((int)(unsigned)(ax >> 32));
         bw_lo = __builtin_amdgcn_readfirstlane((int)(unsigned)aw), bw_hi = __builtin_amdgcn_readfirstlane((int)(unsigned)(aw >> 32));
-        nx = __builtin_amdgcn_readfirstlane((p.up ? p.H >> 1 : p.H) * sw_ * p.C * 2);
+        nx = __builtin_amdgcn_readfirstlane(hp.gimg * (p.up ? p.H >> 1 : p.H) * sw_ * p.C * 2);
         bw_n = __builtin_amdgcn_readfirstlane(n0 + wave * 16 < p.K ? 16 * 9 * p.C * 2 : 0);   // bytes of this wave's 16 weight rows
         return true;
     };
@@ -576,7 +580,10 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     // R[k][f] (set up per tile, moved to the other halo buffer per channel block) and the 16-bit immediate offset Chi: a
     // fragment read costs NO address arithmetic (it was four VALU instructions per read, 32 per wave and phase).
     const int wfrag = (lane & 15) * 64 + (((lane >> 4) * 16) ^ (((lane & 15) >> 3) << 5));
-    const int hb0 = (((wm * PM) >> LGTW) * HWp + ((wm * PM) & (TW - 1)) + (lane & 15)) * 64 + (lane >> 4) * 16;
+    // (stacked images: the wave's rows lie in image (rows before) / H of the tile, whose halo starts two rows per image further down)
+    const int rows_before = (wm * PM) >> LGTW;
+    const int hb0 = ((rows_before + (hp.gimg > 1 ? 2 * (rows_before / p.H) : 0)) * HWp + ((wm * PM) & (TW - 1)) + (lane & 15)) * 64 +
+                    (lane >> 4) * 16;
     // LDS byte addresses (32-bit) of the two halo buffers and the weight ring, for the hand-placed ds_read_b128 below
     const unsigned lds_halo = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)s_halo;
     const unsigned lds_w = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)s_w + wn * 4 * SUB;
@@ -838,15 +845,27 @@ bool halo_geometry(const ConvParams &p, HaloParams &g) {
     while (tw >= 16 && p.W % tw) tw >>= 1;
     if (tw < 16) return false;
     const int th = TP / tw;
-    if (p.H % th) return false;
     g.TW = tw;
     g.TH = th;
     g.lgTW = 0;
     while ((1 << g.lgTW) < tw) g.lgTW++;
-    g.tiles_x = p.W / tw;
-    g.tiles = g.tiles_x * (p.H / th);
     g.HWp = tw + 2;
-    g.nhalo = (th + 2) * (tw + 2);
+    if (p.H % th == 0) {
+        g.gimg = 1;
+        g.hrows = th + 2;
+        g.tiles_x = p.W / tw;
+        g.tiles = g.tiles_x * (p.H / th);
+        g.nhalo = (th + 2) * (tw + 2);
+    } else {
+        // a map lower than the tile (16 x 16: tile 16 wide x 32 rows): th / H whole images per tile, stacked, every wave's 128
+        // pixels inside one of them
+        if (tw != p.W || th % p.H || p.H % (128 / tw) || p.N % (th / p.H) || p.csum) return false;
+        g.gimg = th / p.H;
+        g.hrows = p.H + 2;
+        g.tiles_x = 1;
+        g.tiles = 1;
+        g.nhalo = g.gimg * (p.H + 2) * (tw + 2);
+    }
     g.npieces = (g.nhalo + 15) / 16;
     return g.npieces <= 56;   // at most 7 pieces per wave and channel block
 }
@@ -858,7 +877,7 @@ int launch_halo_inst(const ConvParams &p, const HaloParams &g, hipStream_t st) {
     const int lds = 2 * 56 * SUB + 6 * (128 * 32 * 2);   // two halo buffers of 56 pieces, weight ring of 6 slices
     static const int inst = g_inst_count.fetch_add(1);
     if (const int rc = ensure_attr(reinterpret_cast<const void *>(&k_conv3x3_halo<128, MASK, LGTW>), lds, inst, st)) return rc;
-    const unsigned ptiles = (unsigned)(p.N * g.tiles);
+    const unsigned ptiles = (unsigned)((p.N / g.gimg) * g.tiles);
     const unsigned ids = ((ptiles + 7) / 8) * 8 * (unsigned)((p.K + 127) / 128);   // 8 XCD ranges x ceil(ptiles / 8) x channel tiles
     DevState *ds = dev_state();   // persistent grid: one workgroup per CU (160 KiB of LDS each), a multiple of 8
     if (!ds) return PP_ERR_HIP;
@@ -1370,9 +1389,9 @@ PP_API int pp_conv_own_ex_f16(const void *x, const void *w, const void *bias, co
 // number of splits per image (0: the shape is not taken).  pp_channel_mean_finish_f16 turns the partials into the mean.
 PP_API int pp_conv_own_sums_splits(int h, int wd) {
     ConvParams q;
-    q.R = 3, q.pad = 1, q.dil = 1, q.C = 32, q.K = 128, q.H = h, q.W = wd;
+    q.R = 3, q.pad = 1, q.dil = 1, q.C = 32, q.K = 128, q.H = h, q.W = wd, q.N = 1, q.csum = nullptr;
     HaloParams g;
-    return halo_geometry(q, g) ? g.tiles * 4 : 0;
+    return (halo_geometry(q, g) && g.gimg == 1) ? g.tiles * 4 : 0;
 }
 PP_API int pp_conv_own_sums_f16(const void *x, const void *w, const void *bias, void *y, void *sums_ws, int n, int h, int wd, int c_in,
                                 int c_out, float slope, void *stream) {

@@ -462,6 +462,8 @@ def test_own_implicit_gemm_convolution_matches_torch(shape):
     (1, 64, 256, 32, 96),       # width 96: three 16 x 32 tiles per row band
     (1, 64, 192, 32, 64),       # C_out = 64 mod 128: the second channel tile is half empty (zero weight rows, epilogue skipped)
     (2, 32, 64, 16, 128),       # C_out = 64: one half-empty channel tile
+    (4, 64, 128, 16, 16),       # a 16 x 16 map: two whole images stacked in one 16 x 32 tile, each with its own halo rows
+    (6, 32, 320, 16, 16),       # ... with C_out = 64 mod 128 and an odd number of image pairs
 ])
 def test_halo_tile_3x3_convolution_matches_torch(shape):
     """pp_conv_own_f16 with bn = 512: the 3x3 kernel that keeps the input halo of a 512-pixel tile in LDS and reads the nine
@@ -506,6 +508,7 @@ def test_halo_tile_3x3_convolution_matches_torch(shape):
     (1, 128, 256, 8, 64),       # 128-wide tiles, two output-channel tiles
     (3, 32, 128, 32, 32),       # 64-wide tiles, one channel block
     (1, 64, 128, 8, 96),        # 192-wide output (three 64-wide tiles) read from a 96-wide half-resolution input
+    (4, 64, 128, 8, 8),         # 16 x 16 output (two images per tile) read from an 8 x 8 half-resolution input
 ])
 def test_halo_kernel_upsampled_input_and_two_post_adds(shape):
     """pp_conv_own_ex_f16: the x2 nearest upsample (models/layers_transposed.py:212, :272) read through the 3x3 kernel's halo loads
