@@ -1251,6 +1251,10 @@ __device__ int connect_limb(const Sampler &smp, const LimbLds &L, int nA, int nB
             const unsigned idx = L.c_idx[t];
             const int ia = (int)(idx & 0xffffu), ib = (int)(idx >> 16);
             const int o = ncn + before + __popcll(m & lanemask_lt());
+            // REQUIREMENT of the publication protocol (k_limb_connect): every datum the image's assembly workgroup reads from
+            // this workgroup -- these two rows, the count, the status word -- must leave with a write-through (sc1) store; the
+            // publisher then only drains its stores (vmcnt(0)), meets at the barrier and stores the flag, with no release fence.
+            // A plain store here would sit in this XCD's L2 and the assembly (possibly on another XCD) could read stale bytes.
             store_sc1(conn_out + o, make_float4(__int_as_float(ia), __int_as_float(ib), L.c_score[t], L.c_len[t]));
             // what the assembly needs besides: the two peaks' ids (position in the part-ordered peak line,
             // pafprocess.cpp:34, :43-48) and their scores (pl[id].score, :162, :266)
@@ -1653,7 +1657,7 @@ __device__ __forceinline__ void assemble_compact(const AsmWaveLds &A, int lane, 
 // ready[l] carries this launch's tag in its upper 24 bits (the lower 8: its connection count); the wave polls with
 // agent-scope loads (bounded: PP_ST_SYNC_TIMEOUT), and looks one limb ahead so that a limb that is already published has
 // its connections in flight while the previous limb is assembled (see k_limb_connect for the publishing side).
-constexpr int kSpinMax = 1 << 18;
+constexpr int kSpinMax = 1 << 21;   // polls of ~1.5 us: seconds of ACTIVE waiting (a co-tenant of the GPU may delay the limbs' dispatch) before giving up
 __device__ __forceinline__ unsigned load_flag(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 template <bool STREAM>
