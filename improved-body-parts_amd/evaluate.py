@@ -299,8 +299,12 @@ def run_refactored(a, src, mine, model, post, dev, rank, world):
 
 def run_original(a, src, mine, model, post, dev):
     """evaluate.py:81-89 without --run_refactor: predict + find_peaks + find_connections + find_humans at image resolution,
-    with a real scale search (eager; accumulators at image resolution, so images are bucketed by exact size)."""
-    from posepaf.original_path import OriginalPathProcessor, resize_images_u8
+    with a real scale search.  Accumulators live at image resolution, so images are bucketed by exact size; per batch the images
+    are decoded by a thread pool into a pinned buffer (uploaded while the previous batch computes), every scale runs
+    resize -> pad / normalise / mirror -> forward, and ALL scales are accumulated by one launch (pp_original_accumulate_all).
+    Synthetic runs take their scenes from a device-resident bank per scale (64 scenes), like the refactored path."""
+    from concurrent.futures import ThreadPoolExecutor
+    from posepaf.original_path import OriginalPathProcessor, resize_images_u8, scaled_size
     from posepaf.pipeline import preprocess_batch
     B, scales = a.batch, a.scales or [1.0]
     shapes = [src.shape(int(i)) for i in mine]
@@ -309,21 +313,55 @@ def run_original(a, src, mine, model, post, dev):
         groups.setdefault(hw, []).append(k)
     local = torch.zeros((max(len(mine), 1), RECORD_BYTES), dtype=torch.uint8, device=dev)
     scale = torch.tensor(1e-3, dtype=torch.float16, device=dev)
-    with torch.no_grad():   # untimed warm-up on each bucket shape
-        for key in groups:
-            warm = torch.zeros((B,) + key + (3,), dtype=torch.uint8, device=dev)
+    workers = a.workers or max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8))
+    pool = ThreadPoolExecutor(max_workers=workers)
+    banks = {}
+    with torch.no_grad():   # untimed set-up per image size: convolution shapes of every scale, scene banks
+        for (H, W) in groups:
+            warm = torch.zeros((B, H, W, 3), dtype=torch.uint8, device=dev)
             for sc in scales:
-                model(preprocess_batch(resize_images_u8(warm, float(sc)), True, torch.float16))
+                x = preprocess_batch(resize_images_u8(warm, float(sc)), True, torch.float16)
+                model(x)
+                if src.has_scenes:
+                    fh, fw = x.shape[1] // 4, x.shape[2] // 4
+                    arr = np.stack([synth.make_scene_at_scales(src.n_people(s_), 20_000 + s_, [(fh, fw, float(sc))], img=H)[0][0]
+                                    for s_ in range(SCENE_BANK)])
+                    banks[(H, W, float(sc))] = torch.from_numpy(arr).to(dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    copy_stream = torch.cuda.Stream(device=dev)
     for (H, W), members in groups.items():
         proc = OriginalPathProcessor(post, H, W, B)
-        for b0 in range(0, len(members), B):
-            loc = members[b0:b0 + B]
-            idx = [int(mine[k]) for k in loc]
+        pinned = [torch.zeros((B, H, W, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
+        staged = [torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+        events = [None, None]
+        batches = [members[b0:b0 + B] for b0 in range(0, len(members), B)]
+
+        def stage(j):   # decode batch j into pinned[j % 2] and start its upload on the copy stream
+            if j >= len(batches):
+                return
+            k = j % 2
+            if events[k] is not None:
+                events[k][1].synchronize()          # the compute that read staged[k] two batches ago has finished
+            view = pinned[k].numpy()
+
+            def put(t):
+                view[t[0]] = src.load(int(mine[t[1]]))
+            list(pool.map(put, enumerate(batches[j])))
+            with torch.cuda.stream(copy_stream):
+                staged[k].copy_(pinned[k], non_blocking=True)
+                up = torch.cuda.Event()
+                up.record(copy_stream)
+            events[k] = [up, None]
+
+        stage(0)
+        for j, loc in enumerate(batches):
+            k = j % 2
+            idx = [int(mine[q]) for q in loc]
             n = len(idx)
-            imgs = np.stack([src.load(i) for i in idx] + [np.zeros((H, W, 3), np.uint8)] * (B - n))
-            dev_imgs = torch.from_numpy(imgs).to(dev, non_blocking=True)
+            torch.cuda.current_stream(dev).wait_event(events[k][0])
+            dev_imgs = staged[k]
+            slots = torch.tensor([src.scene_slot(i) for i in idx] + [0] * (B - n), dtype=torch.int64, device=dev) if src.has_scenes else None
             with torch.no_grad():
                 proc.reset()
                 for sc in scales:
@@ -333,16 +371,17 @@ def run_original(a, src, mine, model, post, dev):
                     ph, pw = x.shape[1:3]
                     maps = model(x).contiguous().view(B, 2, 50, ph // 4, pw // 4)
                     if src.has_scenes:   # the same synthetic people, rendered at this scale
-                        szs = [(ph // 4, pw // 4, float(sc))]
-                        inj = np.stack([synth.make_scene_at_scales(src.n_people(src.scene_slot(i)), 20_000 + src.scene_slot(i), szs,
-                                                                   img=H)[0][0] for i in idx] +
-                                       [np.zeros((2, 50, ph // 4, pw // 4), np.float16)] * (B - n))
-                        maps = torch.addcmul(torch.from_numpy(inj).to(dev), maps, scale)
+                        maps = torch.addcmul(banks[(H, W, float(sc))].index_select(0, slots), maps, scale)
                     proc.accumulate(maps, ph - sh, pw - sw, len(scales))
                 rec = proc.finish(B)
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(dev))
+            events[k][1] = done
             local.index_copy_(0, torch.tensor(loc, dtype=torch.int64, device=dev), rec.view(B, RECORD_BYTES)[:n])
+            stage(j + 1)                            # the next batch is decoded and uploaded while this one computes
     torch.cuda.synchronize()
-    return local.view(-1), time.perf_counter() - t0, {"launch": "eager", "scales": scales}
+    pool.shutdown(wait=False)
+    return local.view(-1), time.perf_counter() - t0, {"launch": "eager", "scales": scales, "decode_threads": workers}
 
 
 def main(argv=None):

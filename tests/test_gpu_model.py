@@ -701,6 +701,27 @@ def test_evaluate_two_ranks_over_rccl_when_two_gpus_are_present(tmp_path):
     assert outs[0] == outs[1]
 
 
+def test_evaluate_original_path_with_a_scale_search(tmp_path):
+    """evaluate.py WITHOUT --run_refactor (reference evaluate.py:81-89: predict + find_peaks + find_connections + find_humans) with
+    two scales: pinned double-buffered staging, scene banks per scale, every scale accumulated by one launch; the injected people
+    are recovered at image resolution (records carry PP_ST_FLOAT_COORDS = 32 and nothing else)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import PKG
+    dump = tmp_path / "res.json"
+    r = subprocess.run([sys.executable, os.path.join(PKG, "evaluate.py"), "--synthetic", "5", "--sizes", "192x256", "--batch", "2",
+                        "--scales", "0.5", "1.0", "--people", "2", "3", "--dump_name", str(dump)],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    summary = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert summary["images"] == 5 and summary["status_or"] == 32 and summary["rules"] == "original"
+    res = json.load(open(dump))
+    assert sorted({r_["image_id"] for r_ in res}) == list(range(5)) and len(res) >= 8
+    assert summary["synthetic_oks"]["AP"] > 0.5, summary
+
+
 def test_evaluate_reads_a_coco_annotation_file_and_png_images(tmp_path):
     """The reference's data path (evaluate.py:72, :237-279): annotation JSON + image files in, COCO-format results and the
     keypoint AP against the ANNOTATION's ground truth out.  Offline there are no weights, so --inject_gt adds GT-style maps
