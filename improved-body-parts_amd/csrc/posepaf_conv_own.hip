@@ -42,6 +42,10 @@ struct ConvParams {
     _Float16 *y, *y2;  // y2: second output of mode 4
     const void *zero;  // >= 16 zero bytes: source of every tap that falls outside the image
     int N, H, W, C, K, R, pad, dil, Ho, Wo;
+    int pad_y, pad_x;  // implicit-GEMM kernel: tap (r, s) reads input pixel (oy + r * dil - pad_y, ox + s * dil - pad_x); = pad, except
+                       // for the collapsed upsample convolution below
+    int up_out, py, px;// up_out = 1: the kernel's (n, oy, ox) output pixel is pixel (2 oy + py, 2 ox + px) of y / extra / extra2,
+                       // tensors of twice the size (one output phase of a convolution behind a x2 nearest upsample)
     float *csum;       // NULL, or per-wave partial channel sums of y (halo kernel): [image][tile][4 pixel waves][K] floats -- the SE
                        // block's squeeze (models/layers_transposed.py:298-303) without a pass of its own over y
     int ldy;           // elements between consecutive pixels of y (K: packed; larger: y is a channel slice of a wider tensor,
@@ -355,7 +359,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_igemm(const ConvParams p) {
     int st_r = 0, st_s = 0, st_c = 0;  // tap / 32-channel block of the NEXT phase to stage
     auto stage = [&](int buf) {
         unsigned char *sa = smem + buf * PBUF;
-        const int dy = st_r * p.dil - p.pad, dx = st_s * p.dil - p.pad;
+        const int dy = st_r * p.dil - p.pad_y, dx = st_s * p.dil - p.pad_x;
         const long tapoff = ((long)dy * p.W + dx) * p.C * 2 + (long)st_c * 64;
 #pragma unroll
         for (int i = 0; i < 2; i++) {
@@ -426,7 +430,12 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_igemm(const ConvParams p) {
     // ---- epilogue from registers (16-byte stores: epilogue_store)
     epilogue_store<PT, CT>(acc, p, lane, n0 + wn * 64, [&](int i) -> long {
         const long m = m0 + wm * PM + i * 16 + (lane & 15);
-        return m < p.M ? m : -1;
+        if (m >= p.M) return -1;
+        if (!p.up_out) return m;
+        // one output phase of the collapsed upsample convolution: (n, oy, ox) of the half-resolution grid -> (2 oy + py, 2 ox + px)
+        const int n = (int)(m / HoWo), rem = (int)(m - (long)n * HoWo);
+        const int oy_ = rem / p.Wo, ox_ = rem - oy_ * p.Wo;
+        return ((long)n * (2 * p.Ho) + 2 * oy_ + p.py) * (2 * p.Wo) + 2 * ox_ + p.px;
     }, true);
 }
 
@@ -1360,6 +1369,7 @@ PP_API int pp_conv_own_ex_f16(const void *x, const void *w, const void *bias, co
     p.N = n; p.H = h; p.W = wd; p.C = c_in; p.K = c_out; p.R = ksize; p.pad = pad; p.dil = dilation; p.Ho = ho; p.Wo = wo;
     p.ldy = c_out;
     p.csum = nullptr;
+    p.pad_y = p.pad_x = pad, p.up_out = 0, p.py = p.px = 0;
     p.M = (long)n * ho * wo;
     p.mode = extra_mode;
     p.slope = slope;
@@ -1406,9 +1416,56 @@ PP_API int pp_conv_own_sums_f16(const void *x, const void *w, const void *bias, 
     p.extra = nullptr, p.extra2 = nullptr, p.up = 0, p.y = static_cast<_Float16 *>(y), p.y2 = nullptr, p.zero = nullptr;
     p.N = n, p.H = h, p.W = wd, p.C = c_in, p.K = c_out, p.R = 3, p.pad = 1, p.dil = 1, p.Ho = h, p.Wo = wd;
     p.ldy = c_out, p.csum = static_cast<float *>(sums_ws), p.M = (long)n * h * wd, p.mode = 0, p.slope = slope, p.dbg = 0, p.stagger = -1;
+    p.pad_y = p.pad_x = 1, p.up_out = 0, p.py = p.px = 0;
     HaloParams g;
     if (!halo_geometry(p, g)) return PP_ERR_UNSUPPORTED;
     return launch_halo(p, g, st);
+}
+
+// conv3x3 / pad 1 behind a x2 nearest-neighbour upsample (the hourglass' `hg[i][3](upsample(low))`, models/layers_transposed.py:
+// 270-275) WITHOUT the 2.25x redundant arithmetic: an output pixel (2 y + py, 2 x + px) sees only a 2 x 2 neighbourhood of the
+// half-resolution input, each input pixel through the SUM of the 3x3 taps that land on it --
+//   rows:  py = 0: x[y - 1] * w[0] + x[y] * (w[1] + w[2])      py = 1: x[y] * (w[0] + w[1]) + x[y + 1] * w[2]     (columns alike)
+// -- so the layer is four 2x2 convolutions of the half-resolution tensor (one per output phase, 16 instead of 36 multiply-adds per
+// input pixel), run here as four launches of the implicit-GEMM kernel with asymmetric tap offsets and an interleaving output
+// map.  w4: DEVICE [4 phases: (py, px) = (0,0), (0,1), (1,0), (1,1)][c_out][2][2][c_in] fp16, the tap sums formed by the caller in
+// fp32 and rounded once (same real-number result as the 3x3 on the upsampled tensor; the fp16 rounding of the weights differs).
+// x: DEVICE (n, h_low, w_low, c_in); y / extra / extra2: DEVICE (n, 2 h_low, 2 w_low, c_out).  extra_mode 0, 2 or 3 as
+// pp_conv_own_ex_f16; bn = 256 / 128 / 64 (0: the largest that divides c_out).
+PP_API int pp_conv_up2_collapsed_f16(const void *x, const void *w4, const void *bias, const void *extra, const void *extra2, void *y, int n,
+                                     int h_low, int w_low, int c_in, int c_out, int extra_mode, float slope, int bn, void *stream) {
+    if (!x || !w4 || !bias || !y || n <= 0 || h_low <= 0 || w_low <= 0 || (extra_mode != 0 && extra_mode != 2 && extra_mode != 3) ||
+        (extra_mode != 0) != (extra != nullptr) || (extra_mode == 3) != (extra2 != nullptr))
+        return PP_ERR_BAD_ARG;
+    if (!pp_conv_own_supported(c_in, c_out, 2) || !(slope >= 0.f && slope <= 1.f)) return PP_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w4) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(extra) |
+         reinterpret_cast<uintptr_t>(extra2) | reinterpret_cast<uintptr_t>(y)) & 15)
+        return PP_ERR_BAD_ARG;
+    if (bn == 0) bn = c_out % 256 == 0 ? 256 : (c_out % 128 == 0 ? 128 : 64);
+    if ((bn != 256 && bn != 128 && bn != 64) || c_out % bn) return PP_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    DevState *ds = dev_state();
+    if (!ds) return PP_ERR_HIP;
+    if (!ds->zero) {
+        if (capturing(st)) return PP_ERR_UNSUPPORTED;
+        if (hipMalloc(&ds->zero, 256) != hipSuccess || hipMemset(ds->zero, 0, 256) != hipSuccess) return PP_ERR_HIP;
+    }
+    ConvParams p;
+    p.x = static_cast<const _Float16 *>(x), p.bias = static_cast<const _Float16 *>(bias);
+    p.extra = static_cast<const _Float16 *>(extra), p.extra2 = static_cast<const _Float16 *>(extra2);
+    p.y = static_cast<_Float16 *>(y), p.y2 = nullptr, p.zero = ds->zero, p.up = 0;
+    p.N = n, p.H = h_low, p.W = w_low, p.C = c_in, p.K = c_out, p.R = 2, p.pad = 0, p.dil = 1, p.Ho = h_low, p.Wo = w_low;
+    p.ldy = c_out, p.csum = nullptr, p.M = (long)n * h_low * w_low, p.mode = extra_mode, p.slope = slope, p.dbg = 0, p.stagger = -1;
+    p.up_out = 1;
+    const long wphase = (long)c_out * 4 * c_in;   // halves per phase
+    for (int ph = 0; ph < 4; ph++) {
+        p.py = ph >> 1, p.px = ph & 1;
+        p.pad_y = 1 - p.py, p.pad_x = 1 - p.px;   // taps reach rows {y - 1, y} (py = 0) or {y, y + 1} (py = 1); columns alike
+        p.w = static_cast<const _Float16 *>(w4) + ph * wphase;
+        const int rc = bn == 256 ? launch<256>(p, st) : (bn == 128 ? launch<128>(p, st) : launch<64>(p, st));
+        if (rc != PP_OK) return rc;
+    }
+    return PP_OK;
 }
 
 PP_API int pp_conv_own_f16(const void *x, const void *w, const void *bias, const void *extra, void *y, int n, int h, int wd, int c_in,

@@ -41,6 +41,7 @@ PW_VARIANT = 105            # the streaming 1x1 kernel (pp_pw_f16): weights resi
 USE_PW = True
 USE_SUM_FUSION = True       # the SE block's channel sums leave the 3x3 kernel that produces the feature map
 USE_SLICE_OUTPUT = True     # the backbone's concatenation is written in place by its two producers
+USE_COLLAPSED_UP2 = True    # conv3x3(upsample2(x)) as four 2x2 convolutions of x (2.25x fewer multiply-adds)
 USE_POOL_FUSION = True      # the hourglass' 2x2 max-pools leave the 1x1 kernel that produces their input as a second output
 _conv_choice: dict = {}   # shape key -> tile configuration id, or -1 = MIOpen convolution + k_bias_act pass
 _conv_timing: dict = {}   # shape key -> {"miopen": ms, cfg: ms, ...} measured by the autotune (diagnostics)
@@ -424,15 +425,39 @@ class FConv(nn.Module):
         return best
 
     # ---- x2 nearest upsample in front, up to two tensors added behind: one launch of the 3x3 halo kernel (pp_conv_own_ex_f16)
+    def _collapsed_weights(self):
+        """The 3x3 weights behind a x2 nearest upsample, collapsed per output phase (py, px) into 2x2 weights on the
+        half-resolution grid: an input pixel is reached through the SUM of the taps that land on it (rows: py = 0 ->
+        {w[0], w[1] + w[2]}, py = 1 -> {w[0] + w[1], w[2]}; columns alike).  (4, K, 2, 2, C) fp16, sums in fp32, rounded once."""
+        w4 = getattr(self, "_w4", None)
+        if w4 is None or w4.device != self.weight.device:
+            w = self.weight.detach().float()                                   # (K, C, 3, 3)
+            rows = [[w[:, :, 0], w[:, :, 1] + w[:, :, 2]], [w[:, :, 0] + w[:, :, 1], w[:, :, 2]]]   # [py][a] -> (K, C, 3)
+            out = []
+            for py in range(2):
+                for px in range(2):
+                    taps = []
+                    for a in range(2):
+                        r = rows[py][a]                                         # (K, C, 3): columns still separate
+                        cols = [r[:, :, 0], r[:, :, 1] + r[:, :, 2]] if px == 0 else [r[:, :, 0] + r[:, :, 1], r[:, :, 2]]
+                        taps.append(torch.stack(cols, dim=1))                  # (K, 2 [b], C)
+                    out.append(torch.stack(taps, dim=1))                       # (K, 2 [a], 2 [b], C)
+            w4 = torch.stack(out).to(self.weight.dtype).contiguous()          # (4, K, 2, 2, C)
+            self._w4 = w4
+        return w4
+
     def forward_up2(self, low, post, post2=None):
-        """act(conv(upsample2(low)) + bias) + post (+ post2).  The upsample is read through the convolution's own halo loads
-        and the adds ride on its epilogue when that is faster than upsample2 -> convolution (-> add3), timed once per shape."""
+        """act(conv(upsample2(low)) + bias) + post (+ post2), three ways, the fastest kept per shape (timed once):
+        0 separate: upsample2 -> convolution (-> add3);  1 the upsample read through the 3x3 halo kernel's own loads, adds in its
+        epilogue (pp_conv_own_ex_f16);  2.. the COLLAPSED form (pp_conv_up2_collapsed_f16): four 2x2 convolutions of the
+        half-resolution tensor, 2.25x fewer multiply-adds for the same real-number result (choice = 2 + the tile width index)."""
         from . import _lib
         n, c, h, w = low.shape
         k = self.weight.shape[0]
         key = ("up2", n, c, h, w, k, post2 is not None, bool(self.act))
         fused_ok = (USE_OWN_CONV and low.is_cuda and low.dtype == torch.float16 and self.stride == (1, 1)
                     and tuple(self.weight.shape[2:]) == (3, 3) and self.padding == (1, 1) and self.dilation == (1, 1))
+        COLLAPSED_BN = (256, 128, 64)
 
         def separate():
             if post2 is None:
@@ -449,32 +474,41 @@ class FConv(nn.Module):
                                                 c, k, 3, 1, 1, 3 if post2 is not None else 2, LEAK if self.act else 1.0, 512, 1, _stream(x))
             return y if rc == 0 else None
 
+        def collapsed(bn):
+            if not USE_COLLAPSED_UP2 or k % bn:
+                return None
+            x = _cl(low)
+            y = torch.empty((n, k, 2 * h, 2 * w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            e1, e2 = _cl(post), (_cl(post2) if post2 is not None else None)
+            rc = _lib.load().pp_conv_up2_collapsed_f16(_ptr(x), _ptr(self._collapsed_weights()), _ptr(self.bias), _ptr(e1), _ptr(e2), _ptr(y),
+                                                       n, h, w, c, k, 3 if post2 is not None else 2, LEAK if self.act else 1.0, bn,
+                                                       _stream(x))
+            return y if rc == 0 else None
+
         choice = _conv_choice.get(key) if fused_ok else 0
         if choice is None:
             if torch.cuda.is_current_stream_capturing():
                 return separate()
             separate()                      # tunes the inner convolution's shape first
-            if fused() is None:
-                choice = 0
-            else:
-                def timed(fn):
-                    fn()
-                    torch.cuda.synchronize()
-                    ts = []
-                    for _ in range(_TUNE_REPS):
-                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        e0.record()
-                        fn()
-                        e1.record()
-                        torch.cuda.synchronize()
-                        ts.append(e0.elapsed_time(e1))
-                    return sorted(ts)[len(ts) // 2]
-                t_sep, t_fused = timed(separate), timed(fused)
-                _conv_timing[key] = {"separate": t_sep, "fused": t_fused}
-                choice = 1 if t_fused < t_sep else 0
+            times = {"separate": _timed(separate)}
+            choice, best = 0, times["separate"]
+            if fused() is not None:
+                times["fused"] = _timed(fused)
+                if times["fused"] < best:
+                    choice, best = 1, times["fused"]
+            for i, bn in enumerate(COLLAPSED_BN):
+                if collapsed(bn) is not None:
+                    times[f"collapsed{bn}"] = _timed(lambda: collapsed(bn))
+                    if times[f"collapsed{bn}"] < best:
+                        choice, best = 2 + i, times[f"collapsed{bn}"]
+            _conv_timing[key] = times
             _conv_choice[key] = choice
             _note(key, choice)
-        if choice:
+        if choice >= 2:
+            y = collapsed(COLLAPSED_BN[choice - 2])
+            if y is not None:
+                return y
+        elif choice == 1:
             y = fused()
             if y is not None:
                 return y

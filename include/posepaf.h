@@ -227,6 +227,16 @@ PP_API int pp_conv_own_ex_f16(const void *x, const void *w, const void *bias, co
                               int n, int h, int wd, int c_in, int c_out, int ksize, int pad, int dilation, int extra_mode, float slope,
                               int bn, int upsampled_input, void *stream);
 
+/* A1, the hourglass' `hg[i][3](upsample(low))` (models/layers_transposed.py:270-275): a 3x3 / pad 1 convolution behind a x2
+ * nearest upsample, evaluated as FOUR 2x2 convolutions of the half-resolution tensor (one per output phase): an output pixel
+ * (2y + py, 2x + px) only sees a 2x2 neighbourhood of the input, each input pixel through the sum of the 3x3 taps landing on it --
+ * 16 instead of 36 multiply-adds per input pixel, the same real-number result.  w4: DEVICE [4][c_out][2][2][c_in] fp16, phase
+ * (py, px) = (0,0), (0,1), (1,0), (1,1); rows: py = 0 -> {w[0], w[1] + w[2]} on input rows {y - 1, y}; py = 1 -> {w[0] + w[1], w[2]}
+ * on {y, y + 1}; columns alike (sums formed in fp32, rounded once).  x: (n, h_low, w_low, c_in); y / extra / extra2: (n, 2 h_low,
+ * 2 w_low, c_out); extra_mode 0 / 2 / 3 as pp_conv_own_ex_f16; bn: output channels per workgroup (0, 256, 128, 64). */
+PP_API int pp_conv_up2_collapsed_f16(const void *x, const void *w4, const void *bias, const void *extra, const void *extra2, void *y, int n,
+                                     int h_low, int w_low, int c_in, int c_out, int extra_mode, float slope, int bn, void *stream);
+
 /* A1, the 1x1 convolutions as an HBM-bound stream with the neighbouring element-wise passes folded in (csrc/posepaf_conv_own.hip
  * k_pw):   y = act(conv1x1(x * scale[n]) + bias (+ extra))   [and  y2 = y + extra2]
  * x: DEVICE (m, c_in) fp16 = an NHWC activation of m = n * h * w pixels; scale: DEVICE (m / hw, c_in) fp16 or NULL -- the SE

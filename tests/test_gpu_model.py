@@ -561,6 +561,47 @@ def test_halo_kernel_upsampled_input_and_two_post_adds(shape):
                              n, h, w, ci, co, 3, 1, 1, 3, 0.01, 512, stream) == -2
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 128, 16, 16), (1, 128, 256, 8, 64), (3, 32, 64, 32, 32), (2, 96, 192, 6, 10)])
+def test_collapsed_upsample_convolution_matches_the_convolution_of_the_upsampled_tensor(shape):
+    """pp_conv_up2_collapsed_f16: conv3x3(upsample2(x)) evaluated as four 2x2 convolutions of x with per-phase tap sums
+    (models/layers_transposed.py:270-275; 16 instead of 36 multiply-adds per input pixel).  Against the fp32 convolution of the
+    materialised upsample with the ORIGINAL fp16 weights: the real-number result is the same, the fp16 rounding of the summed
+    weights differs from the rounding of the individual ones -- 4e-3 of the output scale; image borders (zero padding of the
+    upsampled tensor), one and two post adds, every tile width."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from posepaf import _lib, fused_model as fm
+    L = _lib.load()
+    n, ci, co, h, w = shape
+    g = torch.Generator(device="cpu").manual_seed(61)
+    conv = torch.nn.Conv2d(ci, co, 3, 1, 1, bias=True)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) / (ci * 9) ** 0.5)
+        conv.bias.copy_(torch.randn(co, generator=g))
+    f = fm.FConv(conv, None, True).cuda().half()
+    x = torch.randn(n, ci, h, w, generator=g).cuda().half().contiguous(memory_format=torch.channels_last)
+    e1 = torch.randn(n, co, 2 * h, 2 * w, generator=g).cuda().half().contiguous(memory_format=torch.channels_last)
+    e2 = torch.randn(n, co, 2 * h, 2 * w, generator=g).cuda().half().contiguous(memory_format=torch.channels_last)
+    up = F.interpolate(x.float(), scale_factor=2, mode="nearest")
+    act = F.leaky_relu(F.conv2d(up, f.weight.float(), f.bias.float(), 1, 1), 0.01)
+    w4 = f._collapsed_weights()
+    assert w4.shape == (4, co, 2, 2, ci) and w4.dtype == torch.float16
+    vp = C.c_void_p
+    st = vp(torch.cuda.current_stream().cuda_stream)
+    for mode, ref in ((2, act + e1.float()), (3, act.half().float() + e1.float() + e2.float()), (0, act)):
+        for bn in (256, 128, 64):
+            if co % bn:
+                continue
+            y = torch.full((n, co, 2 * h, 2 * w), float("nan"), dtype=torch.float16, device="cuda").contiguous(memory_format=torch.channels_last)
+            rc = L.pp_conv_up2_collapsed_f16(vp(x.data_ptr()), vp(w4.data_ptr()), vp(f.bias.data_ptr()), vp(e1.data_ptr()) if mode else None,
+                                             vp(e2.data_ptr()) if mode == 3 else None, vp(y.data_ptr()), n, h, w, ci, co, mode, 0.01, bn, st)
+            assert rc == 0, (shape, mode, bn, rc)
+            torch.cuda.synchronize()
+            assert torch.isfinite(y).all(), (shape, mode, bn)
+            err = (y.float() - ref).abs().max().item()
+            assert err <= 4e-3 * max(1.0, ref.abs().max().item()), (shape, mode, bn, err)
+
+
 def test_two_output_convolution_matches_convolution_plus_add():
     """pp_conv_own_ex_f16 mode 4 (every own kernel): y must equal the same kernel's mode-1 output bit for bit and y2 must be
     the binary16 sum y + extra2 (models/posenet.py:116-118: cache and x + cache); FConv.forward_dual returns the same pair as

@@ -52,8 +52,8 @@ for tt, key, calls, best, t, tm, tf, gb in rows:
 print("upsample x2 -> 3x3 convolution -> add(s): separate launches vs one launch of the halo kernel, ms")
 for key, t in up2.items():
     _, n, c, h, w, k, two, act = key
-    print(f"  {c:4d}->{k:4d} from {h}x{w} ({'two adds' if two else 'one add'}): separate {t['separate']:.3f}  fused {t['fused']:.3f}  "
-          f"chosen {'fused' if fm._conv_choice[key] else 'separate'}")
+    print(f"  {c:4d}->{k:4d} from {h}x{w} ({'two adds' if two else 'one add'}): " + "  ".join(f"{k_} {v:.3f}" for k_, v in t.items()) +
+          f"  chosen {fm._conv_choice[key]} (0 separate, 1 halo kernel reads the upsample, 2.. collapsed 2x2 form, tile 256 / 128 / 64)")
 print("convolution + second output (y, y + other): separate add vs one launch per own tile width, ms")
 for key, t in fm._conv_timing.items():
     if key[0] == "dual":
