@@ -49,6 +49,10 @@ FLOP_PER_FORWARD_REFERENCE = 529.39e9                                   # SURVEY
 FLOP_PER_FORWARD_EXECUTED = 512.18e9                                    # tools/count_flops.py: the inference model (the last
 #                                                                         stage's unused coarse heads are not computed)
 FLOP_PER_IMAGE = 2 * FLOP_PER_FORWARD_EXECUTED                          # flip: two forwards per image
+# the 3x3 convolutions behind a x2 upsample (4 stages x hourglass levels 0..3: 256 ch @128^2, 384 @64^2, 512 @32^2, 640 @16^2 outputs):
+# 2 * H * W * C^2 * 9 each; the collapsed 2x2 form (posepaf/fused_model.py forward_up2) multiplies out 4/9 of that
+UP2_FLOP_PER_FORWARD = 4 * 2 * 9 * (128 * 128 * 256 * 256 + 64 * 64 * 384 * 384 + 32 * 32 * 512 * 512 + 16 * 16 * 640 * 640)
+UP2_FLOP_SAVED_PER_FORWARD = UP2_FLOP_PER_FORWARD * 5 / 9
 ST_DEFINED, ST_SORT_UNDEFINED = 0x7F, 8                                 # include/posepaf.h:53-61
 
 
@@ -510,9 +514,13 @@ class GpuEngine:
             out["roofline_forward"] = {
                 "bound": "mfma", "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F16_PEAK_TFLOPS,
                 "flop_per_forward": FLOP_PER_FORWARD_EXECUTED,
-                "note": "whole step time (ingest + forward + pre/post-processing) against the dense fp16 MFMA peak; FLOPs are "
-                        "those the inference model executes (512.18 GFLOP per 512x512 forward, tools/count_flops.py), not the "
-                        "reference module's 529.39 (its last stage's coarse heads are computed and discarded)"}
+                "flop_per_forward_multiplied_out": FLOP_PER_FORWARD_EXECUTED - UP2_FLOP_SAVED_PER_FORWARD,
+                "note": "whole step time (ingest + forward + pre/post-processing) against the dense fp16 MFMA peak; ALGORITHMIC FLOPs: "
+                        "those of the inference model's convolutions as the reference defines them (512.18 GFLOP per 512x512 forward, "
+                        "tools/count_flops.py; the reference module's 529.39 include last-stage coarse heads that are computed and "
+                        "discarded).  Since round 3 the hourglass' conv3x3(upsample2(x)) layers are evaluated as four 2x2 convolutions "
+                        "of x (per-phase tap sums: the same real-number result with 2.25x fewer multiply-adds), so the matrix units "
+                        "multiply out about flop_per_forward_multiplied_out per forward when every such site takes that form"}
             if not a.plain_model:
                 from posepaf import fused_model
                 ch = fused_model.conv_choices()

@@ -465,8 +465,13 @@ struct HaloParams {
 // DIAGNOSTIC (MASK bit 1024): shader clock / 100 MHz reference clock stamps around the main loop of each workgroup's first tile
 __device__ unsigned long long g_conv_clk[8 * 512];
 
-template <int BN, int MASK, int LGTW>
+// PH: -1 = the 3x3 convolution (nine taps per channel block).  0..3 = output phase (py, px) = (PH >> 1, PH & 1) of the COLLAPSED
+// upsample convolution (pp_conv_up2_collapsed_f16): the input is the half-resolution tensor, the weights are (K, 2, 2, C) tap sums,
+// only the FOUR taps of the 3x3 neighbourhood that phase sees are walked -- rows PH >> 1 + {0, 1}, columns PH & 1 + {0, 1} of the
+// same halo -- and output pixel (y, x) of the tile lands at (2 y + py, 2 x + px) of a tensor twice the size.
+template <int BN, int MASK, int LGTW, int PH = -1>
 __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, const HaloParams hp) {
+    constexpr int NT = PH < 0 ? 9 : 4;   // taps per channel block
     // The tile geometry is a template parameter: every fragment address is then "lane register + immediate" (see R[][] below).
     constexpr int TW = 1 << LGTW, HWp = TW + 2, TH = TP / TW;
     constexpr int dbg = MASK;  // ablation switches are COMPILE-TIME (a runtime switch costs a branch per guarded instruction); 0 in production
@@ -547,15 +552,15 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
         }
         const int b = ln * 16;
         const int bs = b ^ (((b >> 9) & 1) << 5);
-        woff = (unsigned)((bs >> 6) * (9 * p.C * 2) + (bs & 63));   // lane part: row of the sub-tile, byte inside the 32-half k slice
+        woff = (unsigned)((bs >> 6) * (NT * p.C * 2) + (bs & 63));   // lane part: row of the sub-tile, byte inside the 32-half k slice
         // buffer resources (scalar): this image (bounds = the image: border pixels read zeros), this wave's 16 weight rows
         // (kept as explicitly wave-uniform dwords: a resource the compiler cannot prove uniform costs a waterfall loop per load)
         const unsigned long long ax = reinterpret_cast<unsigned long long>(xb);
-        const unsigned long long aw = reinterpret_cast<unsigned long long>(wb) + (unsigned long long)((long)(n0 + wave * 16) * (9L * p.C * 2));
+        const unsigned long long aw = reinterpret_cast<unsigned long long>(wb) + (unsigned long long)((long)(n0 + wave * 16) * ((long)NT * p.C * 2));
         bx_lo = __builtin_amdgcn_readfirstlane((int)(unsigned)ax), bx_hi = __builtin_amdgcn_readfirstlane((int)(unsigned)(ax >> 32));
         bw_lo = __builtin_amdgcn_readfirstlane((int)(unsigned)aw), bw_hi = __builtin_amdgcn_readfirstlane((int)(unsigned)(aw >> 32));
         nx = __builtin_amdgcn_readfirstlane(hp.gimg * (p.up ? p.H >> 1 : p.H) * sw_ * p.C * 2);
-        bw_n = __builtin_amdgcn_readfirstlane(n0 + wave * 16 < p.K ? 16 * 9 * p.C * 2 : 0);   // bytes of this wave's 16 weight rows
+        bw_n = __builtin_amdgcn_readfirstlane(n0 + wave * 16 < p.K ? 16 * NT * p.C * 2 : 0);   // bytes of this wave's 16 weight rows
         return true;
     };
     auto next_tile = [&](int id) -> int {   // first valid id at or after `id` on this workgroup's stride, or total_ids
@@ -564,14 +569,14 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     };
 
     const int ncb = p.C / 32;
-    const int np = ncb * 9;
+    const int np = ncb * NT;
     int st_cb = 0, st_tap = 0;   // (channel block, tap) of the NEXT weight slice to stage
     int st_slot = 0;
     int slot_cur = 0;            // ring slot of the phase being multiplied
     auto stage_w = [&]() {
         lds_dma16_buf(rsrc_of(bw_lo, bw_hi, bw_n), woff, (unsigned)((st_tap * p.C + st_cb * 32) * 2), s_w + st_slot * WB + wave * SUB);
         if (++st_slot == NW) st_slot = 0;
-        if (++st_tap == 9) {
+        if (++st_tap == NT) {
             st_tap = 0;
             ++st_cb;
         }
@@ -613,7 +618,8 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     };
     auto xread = [&](auto TAP, auto I, half8_t &dst) {   // pixel fragment of (tap, pixel tile i) from the halo buffer R points to
         constexpr int tap = decltype(TAP)::value, i = decltype(I)::value;
-        constexpr int Cpix = (tap / 3) * HWp + tap % 3 + ((i * 16) >> LGTW) * HWp + ((i * 16) & (TW - 1));
+        constexpr int trow = PH < 0 ? tap / 3 : (PH >> 1) + (tap >> 1), tcol = PH < 0 ? tap % 3 : (PH & 1) + (tap & 1);
+        constexpr int Cpix = trow * HWp + tcol + ((i * 16) >> LGTW) * HWp + ((i * 16) & (TW - 1));
         constexpr int C = Cpix * 64, k = Cpix & 3, Chi = C & ~255, f = (Chi >> 8) & 1;
         static_assert(Chi < 65536, "16-bit DS offset");
         lds_read16<Chi>(dst, R[k][f]);
@@ -693,8 +699,10 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     auto phase = [&](auto TAP, auto HALO, int cb) {
         constexpr int tap = decltype(TAP)::value;
         constexpr bool halo = decltype(HALO)::value;     // a next channel block exists: its halo streams in
-        constexpr int ntap = tap == 8 ? 0 : tap + 1;
-        constexpr auto halo_at = [](int t) { return t < 0 ? 0 : (t <= 1 ? 2 : (t <= 4 ? 1 : 0)); };
+        constexpr int ntap = tap == NT - 1 ? 0 : tap + 1;
+        // halo pieces issued per tap.  A piece is waited for KEEP = 3 taps after its issue and must have landed when the block ends:
+        // nine taps spread them 2-2-1-1-1 over taps 0..4, four taps issue all seven at tap 0.
+        constexpr auto halo_at = [](int t) { return t < 0 ? 0 : (NT == 9 ? (t <= 1 ? 2 : (t <= 4 ? 1 : 0)) : (t == 0 ? 7 : 0)); };
         constexpr int in_flight = KEEP + (halo ? halo_at(tap) + halo_at(tap - 1) + halo_at(tap - 2) : 0);
         static_assert(KEEP == 3, "in_flight sums the halo pieces of three taps");
         // The two waves of a SIMD (w and w + 4) issue their DMA at different times: a piece blocks its wave for 60-100 cycles, and
@@ -702,7 +710,17 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
         auto issue_dma = [&]() {
             if (!(dbg & 1)) {
                 if (halo) {
-                    if (tap <= 1) {
+                    if (NT == 4) {
+                        if (tap == 0) {
+                            stage_halo(0, cb + 1, (cb + 1) & 1);
+                            stage_halo(1, cb + 1, (cb + 1) & 1);
+                            stage_halo(2, cb + 1, (cb + 1) & 1);
+                            stage_halo(3, cb + 1, (cb + 1) & 1);
+                            stage_halo(4, cb + 1, (cb + 1) & 1);
+                            stage_halo(5, cb + 1, (cb + 1) & 1);
+                            stage_halo(6, cb + 1, (cb + 1) & 1);
+                        }
+                    } else if (tap <= 1) {
                         stage_halo(2 * tap, cb + 1, (cb + 1) & 1);
                         stage_halo(2 * tap + 1, cb + 1, (cb + 1) & 1);
                     } else if (tap <= 4) {
@@ -738,7 +756,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
         tile_a(std::integral_constant<int, 6>{});
         tile_a(std::integral_constant<int, 7>{});
         static_assert(PT == 8, "eight pixel tiles per wave");
-        constexpr bool refill = !(dbg & 4) && !(tap == 8 && !halo);   // the last phase of all has no successor (a read whose
+        constexpr bool refill = !(dbg & 4) && !(tap == NT - 1 && !halo);   // the last phase of all has no successor (a read whose
                                                                       // result nobody waits for may land in a re-used register)
         if (grp != 0 && !(dbg & 128)) issue_dma();
         if (refill) {
@@ -746,7 +764,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
             lds_read16<SUB>(wf[1], sw_nxt);
         }
         wait_lgkmcnt<refill ? 2 : 0>();
-        if (refill && tap == 8) flip_R((cb + 1) & 1);   // the next phase is tap 0 of the next channel block: the other halo buffer
+        if (refill && tap == NT - 1) flip_R((cb + 1) & 1);   // the next phase is tap 0 of the next channel block: the other halo buffer
         auto tile_b = [&](auto I) {
             constexpr int i = decltype(I)::value;
             if (!(dbg & 2)) {
@@ -774,11 +792,13 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
         phase(std::integral_constant<int, 1>{}, HALO, cb);
         phase(std::integral_constant<int, 2>{}, HALO, cb);
         phase(std::integral_constant<int, 3>{}, HALO, cb);
-        phase(std::integral_constant<int, 4>{}, HALO, cb);
-        phase(std::integral_constant<int, 5>{}, HALO, cb);
-        phase(std::integral_constant<int, 6>{}, HALO, cb);
-        phase(std::integral_constant<int, 7>{}, HALO, cb);
-        phase(std::integral_constant<int, 8>{}, HALO, cb);
+        if constexpr (NT == 9) {
+            phase(std::integral_constant<int, 4>{}, HALO, cb);
+            phase(std::integral_constant<int, 5>{}, HALO, cb);
+            phase(std::integral_constant<int, 6>{}, HALO, cb);
+            phase(std::integral_constant<int, 7>{}, HALO, cb);
+            phase(std::integral_constant<int, 8>{}, HALO, cb);
+        }
     };
     for (int cb = 0; cb + 1 < ncb; cb++) block(std::true_type{}, cb);
     block(std::false_type{}, ncb - 1);
@@ -803,6 +823,8 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     epilogue_store<PT, CT>(acc, p, lane, c_n0 + wn * 64, [&](int i) -> long {
         const int q = wm * PM + i * 16 + (lane & 15);
         const int qy = q >> LGTW, qx = q & (TW - 1);
+        if (PH >= 0)   // collapsed upsample convolution: this phase's place in the tensor of twice the size (rows counted globally)
+            return (2 * ((long)c_img * p.H + c_ty0 + qy) + (PH >> 1)) * (2 * p.W) + 2 * (c_tx0 + qx) + (PH & 1);
         return ((long)c_img * p.H + c_ty0 + qy) * p.W + c_tx0 + qx;
     }, !(dbg & 8), p.csum ? p.csum + (((long)c_img * hp.tiles + c_tile) * WM + wm) * p.K : nullptr);
     stamp(4);            // 4: epilogue (issue)
@@ -816,7 +838,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
 // reads out-of-image taps from, the CU count of the persistent grid, and which kernel instances have had their dynamic-LDS
 // attribute raised on that device.  Indexed by hipGetDevice(); initialisation allocates, so it refuses to run inside a stream
 // capture (PP_ERR_UNSUPPORTED: call the entry point once eagerly first, as every warm-up does).
-constexpr int kMaxDevices = 32, kMaxInst = 24;
+constexpr int kMaxDevices = 32, kMaxInst = 64;
 struct DevState {
     void *zero = nullptr;
     int ncu = 0;
@@ -881,11 +903,11 @@ bool halo_geometry(const ConvParams &p, HaloParams &g) {
 
 
 
-template <int MASK, int LGTW>
+template <int MASK, int LGTW, int PH = -1>
 int launch_halo_inst(const ConvParams &p, const HaloParams &g, hipStream_t st) {
     const int lds = 2 * 56 * SUB + 6 * (128 * 32 * 2);   // two halo buffers of 56 pieces, weight ring of 6 slices
     static const int inst = g_inst_count.fetch_add(1);
-    if (const int rc = ensure_attr(reinterpret_cast<const void *>(&k_conv3x3_halo<128, MASK, LGTW>), lds, inst, st)) return rc;
+    if (const int rc = ensure_attr(reinterpret_cast<const void *>(&k_conv3x3_halo<128, MASK, LGTW, PH>), lds, inst, st)) return rc;
     const unsigned ptiles = (unsigned)((p.N / g.gimg) * g.tiles);
     const unsigned ids = ((ptiles + 7) / 8) * 8 * (unsigned)((p.K + 127) / 128);   // 8 XCD ranges x ceil(ptiles / 8) x channel tiles
     DevState *ds = dev_state();   // persistent grid: one workgroup per CU (160 KiB of LDS each), a multiple of 8
@@ -906,9 +928,9 @@ int launch_halo_inst(const ConvParams &p, const HaloParams &g, hipStream_t st) {
     if (q.stagger < 0) {   // default: spread the starts over half a tile's time (np phases of ~1500 cycles), less when a workgroup has few tiles
         const float rounds = (float)ids / (float)grid.x;
         const float f = 0.5f * (rounds < 32.f ? rounds / 32.f : 1.f);
-        q.stagger = grid.x < ids ? (int)(f * (float)(p.C / 32 * 9) * 1500.f / 8128.f + 0.5f) : 0;
+        q.stagger = grid.x < ids ? (int)(f * (float)(p.C / 32 * (PH < 0 ? 9 : 4)) * 1500.f / 8128.f + 0.5f) : 0;
     }
-    hipLaunchKernelGGL((k_conv3x3_halo<128, MASK, LGTW>), grid, dim3(NTHREADS), lds, st, q, g);
+    hipLaunchKernelGGL((k_conv3x3_halo<128, MASK, LGTW, PH>), grid, dim3(NTHREADS), lds, st, q, g);
     return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
 }
 
@@ -921,6 +943,17 @@ int launch_halo_mask(const ConvParams &p, const HaloParams &g, hipStream_t st) {
         if (g.lgTW == 4) return launch_halo_inst<0, 4>(p, g, st);
     }
     return PP_ERR_UNSUPPORTED;
+}
+
+template <int PH>
+int launch_halo_phase(const ConvParams &p, const HaloParams &g, hipStream_t st) {
+    switch (g.lgTW) {
+        case 7: return launch_halo_inst<0, 7, PH>(p, g, st);
+        case 6: return launch_halo_inst<0, 6, PH>(p, g, st);
+        case 5: return launch_halo_inst<0, 5, PH>(p, g, st);
+        case 4: return launch_halo_inst<0, 4, PH>(p, g, st);
+        default: return PP_ERR_UNSUPPORTED;
+    }
 }
 
 int launch_halo(const ConvParams &p, const HaloParams &g, hipStream_t st) {
@@ -1441,9 +1474,28 @@ PP_API int pp_conv_up2_collapsed_f16(const void *x, const void *w4, const void *
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w4) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(extra) |
          reinterpret_cast<uintptr_t>(extra2) | reinterpret_cast<uintptr_t>(y)) & 15)
         return PP_ERR_BAD_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (bn == 512) {   // the halo-tile kernel walking only the four taps each output phase sees (k_conv3x3_halo<..., PH>)
+        ConvParams q;
+        q.x = static_cast<const _Float16 *>(x), q.bias = static_cast<const _Float16 *>(bias);
+        q.extra = static_cast<const _Float16 *>(extra), q.extra2 = static_cast<const _Float16 *>(extra2);
+        q.y = static_cast<_Float16 *>(y), q.y2 = nullptr, q.zero = nullptr, q.up = 0;
+        q.N = n, q.H = h_low, q.W = w_low, q.C = c_in, q.K = c_out, q.R = 3, q.pad = 1, q.dil = 1, q.Ho = h_low, q.Wo = w_low;
+        q.ldy = c_out, q.csum = nullptr, q.M = (long)n * h_low * w_low, q.mode = extra_mode, q.slope = slope, q.dbg = 0, q.stagger = -1;
+        q.pad_y = q.pad_x = 1, q.up_out = 1, q.py = q.px = 0;
+        HaloParams g;
+        if (!halo_geometry(q, g)) return PP_ERR_UNSUPPORTED;
+        const long wphase = (long)c_out * 4 * c_in;
+        for (int ph = 0; ph < 4; ph++) {
+            q.w = static_cast<const _Float16 *>(w4) + ph * wphase;
+            const int rc = ph == 0 ? launch_halo_phase<0>(q, g, st) : (ph == 1 ? launch_halo_phase<1>(q, g, st) :
+                           (ph == 2 ? launch_halo_phase<2>(q, g, st) : launch_halo_phase<3>(q, g, st)));
+            if (rc != PP_OK) return rc;
+        }
+        return PP_OK;
+    }
     if (bn == 0) bn = c_out % 256 == 0 ? 256 : (c_out % 128 == 0 ? 128 : 64);
     if ((bn != 256 && bn != 128 && bn != 64) || c_out % bn) return PP_ERR_UNSUPPORTED;
-    hipStream_t st = static_cast<hipStream_t>(stream);
     DevState *ds = dev_state();
     if (!ds) return PP_ERR_HIP;
     if (!ds->zero) {

@@ -457,7 +457,7 @@ class FConv(nn.Module):
         key = ("up2", n, c, h, w, k, post2 is not None, bool(self.act))
         fused_ok = (USE_OWN_CONV and low.is_cuda and low.dtype == torch.float16 and self.stride == (1, 1)
                     and tuple(self.weight.shape[2:]) == (3, 3) and self.padding == (1, 1) and self.dilation == (1, 1))
-        COLLAPSED_BN = (256, 128, 64)
+        COLLAPSED_BN = (256, 128, 64, 512)   # 512: the halo-tile kernel walking the four taps of each output phase
 
         def separate():
             if post2 is None:
@@ -475,7 +475,7 @@ class FConv(nn.Module):
             return y if rc == 0 else None
 
         def collapsed(bn):
-            if not USE_COLLAPSED_UP2 or k % bn:
+            if not USE_COLLAPSED_UP2 or k % (bn if bn != 512 else 64):
                 return None
             x = _cl(low)
             y = torch.empty((n, k, 2 * h, 2 * w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)

@@ -561,7 +561,8 @@ def test_halo_kernel_upsampled_input_and_two_post_adds(shape):
                              n, h, w, ci, co, 3, 1, 1, 3, 0.01, 512, stream) == -2
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 128, 16, 16), (1, 128, 256, 8, 64), (3, 32, 64, 32, 32), (2, 96, 192, 6, 10)])
+@pytest.mark.parametrize("shape", [(2, 64, 128, 16, 16), (1, 128, 256, 8, 64), (3, 32, 64, 32, 32), (2, 96, 192, 6, 10),
+                                   (1, 64, 128, 8, 128), (2, 128, 128, 32, 32)])
 def test_collapsed_upsample_convolution_matches_the_convolution_of_the_upsampled_tensor(shape):
     """pp_conv_up2_collapsed_f16: conv3x3(upsample2(x)) evaluated as four 2x2 convolutions of x with per-phase tap sums
     (models/layers_transposed.py:270-275; 16 instead of 36 multiply-adds per input pixel).  Against the fp32 convolution of the
@@ -589,8 +590,8 @@ def test_collapsed_upsample_convolution_matches_the_convolution_of_the_upsampled
     vp = C.c_void_p
     st = vp(torch.cuda.current_stream().cuda_stream)
     for mode, ref in ((2, act + e1.float()), (3, act.half().float() + e1.float() + e2.float()), (0, act)):
-        for bn in (256, 128, 64):
-            if co % bn:
+        for bn in (256, 128, 64, 512):   # 512: the halo-tile kernel (maps it takes: width a multiple of 16, ...)
+            if co % (bn if bn != 512 else 64) or (bn == 512 and (w % 16 or h % 8)):
                 continue
             y = torch.full((n, co, 2 * h, 2 * w), float("nan"), dtype=torch.float16, device="cuda").contiguous(memory_format=torch.channels_last)
             rc = L.pp_conv_up2_collapsed_f16(vp(x.data_ptr()), vp(w4.data_ptr()), vp(f.bias.data_ptr()), vp(e1.data_ptr()) if mode else None,
