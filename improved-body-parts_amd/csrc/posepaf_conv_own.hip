@@ -219,14 +219,14 @@ __device__ __forceinline__ void epilogue_preloaded(const float4_t (&acc)[PT][CT]
                     if (MODE == 2) t += x;
                     out[2 * e] = (_Float16)t[0];
                     out[2 * e + 1] = (_Float16)t[1];
-                    if (MODE == 4) {
+                    if (MODE == 4 || MODE == 5) {
                         out2[2 * e] = (_Float16)((float)out[2 * e] + (float)ev2[2 * e]);
                         out2[2 * e + 1] = (_Float16)((float)out[2 * e + 1] + (float)ev2[2 * e + 1]);
                     }
                 }
                 *reinterpret_cast<half8_t *>(p.y + (m * p.ldy + co)) = out;
-                if (MODE == 4) *reinterpret_cast<half8_t *>(p.y2 + (m * p.K + co)) = out2;
-                keep[i] = MODE == 4 ? out2 : out;
+                if (MODE == 4 || MODE == 5) *reinterpret_cast<half8_t *>(p.y2 + (m * p.K + co)) = out2;
+                keep[i] = (MODE == 4 || MODE == 5) ? out2 : out;
             }
         }
         if (POOL) {
@@ -1081,8 +1081,8 @@ __global__ __launch_bounds__(512) void k_pw(const PwParams p) {
 #pragma unroll
                     for (int jp = 0; jp < 2; jp++) {
                         const long o = mm * p.e.K + n_base + c0 + (2 * jp + odd) * 16 + cbase;
-                        pre[i][jp] = p.e.mode != 0 ? *reinterpret_cast<const half8_t *>(p.e.extra + o) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
-                        pre2[i][jp] = p.e.mode == 4 ? *reinterpret_cast<const half8_t *>(p.e.extra2 + o) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+                        pre[i][jp] = (p.e.mode != 0 && p.e.mode != 5) ? *reinterpret_cast<const half8_t *>(p.e.extra + o) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+                        pre2[i][jp] = p.e.mode >= 4 ? *reinterpret_cast<const half8_t *>(p.e.extra2 + o) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
                     }
                 }
             }
@@ -1105,11 +1105,13 @@ __global__ __launch_bounds__(512) void k_pw(const PwParams p) {
                 if (p.e.mode == 0) epilogue_preloaded<0, PT, 4, true>(acc, p.e, lane, n_base + c0, pix, pre, pre2, p.pool, pb);
                 else if (p.e.mode == 1) epilogue_preloaded<1, PT, 4, true>(acc, p.e, lane, n_base + c0, pix, pre, pre2, p.pool, pb);
                 else if (p.e.mode == 2) epilogue_preloaded<2, PT, 4, true>(acc, p.e, lane, n_base + c0, pix, pre, pre2, p.pool, pb);
-                else epilogue_preloaded<4, PT, 4, true>(acc, p.e, lane, n_base + c0, pix, pre, pre2, p.pool, pb);
+                else if (p.e.mode == 4) epilogue_preloaded<4, PT, 4, true>(acc, p.e, lane, n_base + c0, pix, pre, pre2, p.pool, pb);
+                else epilogue_preloaded<5, PT, 4, true>(acc, p.e, lane, n_base + c0, pix, pre, pre2, p.pool, pb);
             } else if (p.e.mode == 0) epilogue_preloaded<0, PT, 4, false>(acc, p.e, lane, n_base + c0, pix, pre, pre2);
             else if (p.e.mode == 1) epilogue_preloaded<1, PT, 4, false>(acc, p.e, lane, n_base + c0, pix, pre, pre2);
             else if (p.e.mode == 2) epilogue_preloaded<2, PT, 4, false>(acc, p.e, lane, n_base + c0, pix, pre, pre2);
-            else epilogue_preloaded<4, PT, 4, false>(acc, p.e, lane, n_base + c0, pix, pre, pre2);
+            else if (p.e.mode == 4) epilogue_preloaded<4, PT, 4, false>(acc, p.e, lane, n_base + c0, pix, pre, pre2);
+            else epilogue_preloaded<5, PT, 4, false>(acc, p.e, lane, n_base + c0, pix, pre, pre2);
         }
     }
 }
@@ -1277,8 +1279,10 @@ PP_API int pp_pw_pool_f16(const void *x, const void *scale, const void *w, const
 
 static int pw_run(const void *x, const void *scale, const void *w, const void *bias, const void *extra, const void *extra2, void *y,
                   void *y2, long m, int hw, int c_in, int c_out, int ldy, int extra_mode, float slope, void *pool, int width, void *stream) {
-    if (!x || !w || !bias || !y || m <= 0 || hw <= 0 || ldy < c_out || extra_mode < 0 || extra_mode == 3 || extra_mode > 4 ||
-        (extra_mode != 0) != (extra != nullptr) || (extra_mode == 4) != (extra2 != nullptr) || (extra_mode == 4) != (y2 != nullptr))
+    // extra_mode 5 (this kernel only): the second output y2 = y + extra2 WITHOUT a tensor added before the activation
+    if (!x || !w || !bias || !y || m <= 0 || hw <= 0 || ldy < c_out || extra_mode < 0 || extra_mode == 3 || extra_mode > 5 ||
+        (extra_mode != 0 && extra_mode != 5) != (extra != nullptr) || (extra_mode >= 4) != (extra2 != nullptr) ||
+        (extra_mode >= 4) != (y2 != nullptr))
         return PP_ERR_BAD_ARG;
     if (!pp_pw_supported(c_in, c_out) || !(slope >= 0.f && slope <= 1.f) || (ldy & 7)) return PP_ERR_UNSUPPORTED;
     if (scale && (hw & 63)) return PP_ERR_UNSUPPORTED;

@@ -42,6 +42,7 @@ USE_PW = True
 USE_SUM_FUSION = True       # the SE block's channel sums leave the 3x3 kernel that produces the feature map
 USE_SLICE_OUTPUT = True     # the backbone's concatenation is written in place by its two producers
 USE_COLLAPSED_UP2 = True    # conv3x3(upsample2(x)) as four 2x2 convolutions of x (2.25x fewer multiply-adds)
+USE_FOLDED_MERGE = True     # merge_preds(head(f)) is linear in f: folded into merge_features' weights at load time
 USE_POOL_FUSION = True      # the hourglass' 2x2 max-pools leave the 1x1 kernel that produces their input as a second output
 _conv_choice: dict = {}   # shape key -> tile configuration id, or -1 = MIOpen convolution + k_bias_act pass
 _conv_timing: dict = {}   # shape key -> {"miopen": ms, cfg: ms, ...} measured by the autotune (diagnostics)
@@ -526,7 +527,9 @@ class FConv(nn.Module):
         k, r = self.weight.shape[0], self.weight.shape[2]
         pool_ok = want_pool and USE_POOL_FUSION and h % 2 == 0 and w % (64 if c == 64 else 32) == 0
         key = ("dual", n, c, h, w, k, r, self.padding[0], self.dilation[0], bool(self.act), scale is not None, pool_ok)
-        ok = (USE_OWN_CONV and x.is_cuda and x.dtype == torch.float16 and self.stride == (1, 1) and res is not None
+        if res is None:
+            key = key + ("nores",)
+        ok = (USE_OWN_CONV and x.is_cuda and x.dtype == torch.float16 and self.stride == (1, 1)
               and self.weight.shape[2] == self.weight.shape[3] and self.padding[0] == self.padding[1] and self.dilation[0] == self.dilation[1]
               and 2 * self.padding[0] == self.dilation[0] * (r - 1) and _lib.load().pp_conv_own_supported(c, k, r))
 
@@ -536,7 +539,10 @@ class FConv(nn.Module):
             return (y, y2, maxpool2(y2)) if want_pool else (y, y2)
 
         def fused(bn):
-            xx, rr, oo = _cl(x), _cl(res), _cl(other)
+            if res is None and bn != PW_VARIANT:
+                return None                  # only the streaming 1x1 kernel has the two-output form without a residual (mode 5)
+            xx, rr, oo = _cl(x), (_cl(res) if res is not None else None), _cl(other)
+            dmode = 4 if res is not None else 5
             if not self.weight.is_contiguous(memory_format=torch.channels_last):
                 self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
             y = torch.empty((n, k, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
@@ -547,11 +553,11 @@ class FConv(nn.Module):
                 if pool_ok:   # ... and the 2x2 max-pool of y2 (the next stage's hourglass pools its input first)
                     pooled = torch.empty((n, k, h // 2, w // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
                     rc = _lib.load().pp_pw_pool_f16(_ptr(xx), _ptr(scale), _ptr(self.weight), _ptr(self.bias), _ptr(rr), _ptr(oo),
-                                                    _ptr(y), _ptr(y2), _ptr(pooled), n * h * w, h * w, w, c, k, k, 4,
+                                                    _ptr(y), _ptr(y2), _ptr(pooled), n * h * w, h * w, w, c, k, k, dmode,
                                                     LEAK if self.act else 1.0, _stream(x))
                     return (y, y2, pooled) if rc == 0 else None
                 rc = _lib.load().pp_pw_f16(_ptr(xx), _ptr(scale), _ptr(self.weight), _ptr(self.bias), _ptr(rr), _ptr(oo), _ptr(y),
-                                           _ptr(y2), n * h * w, h * w, c, k, k, 4, LEAK if self.act else 1.0, _stream(x))
+                                           _ptr(y2), n * h * w, h * w, c, k, k, dmode, LEAK if self.act else 1.0, _stream(x))
                 if rc != 0:
                     return None
                 return (y, y2, maxpool2(y2)) if want_pool else (y, y2)
@@ -921,9 +927,21 @@ class FusedIMHN(nn.Module):
         self.mfeat = nn.ModuleList([nn.ModuleList([_fconv_from_block(m.conv) for m in ms]) for ms in p.merge_features])
         self.mpred = nn.ModuleList([nn.ModuleList([_fconv_from_block(m.conv) for m in ms]) for ms in p.merge_preds])
         # cache_s = merge_pred(pred) + merge_feat(feat): both are bias-only 1x1 convs -> one epilogue with the summed bias
-        for mf, mp in zip(self.mfeat, self.mpred):
-            for f, q in zip(mf, mp):
+        self.folded_merge = bool(USE_FOLDED_MERGE)
+        for t_, (mf, mp) in enumerate(zip(self.mfeat, self.mpred)):
+            for s_, (f, q) in enumerate(zip(mf, mp)):
                 f.bias = nn.Parameter(f.bias + q.bias, requires_grad=False)
+                if self.folded_merge:
+                    # cache = merge_features(feat) + merge_preds(head(feat))  (models/posenet.py:116-117) and both merge_preds and
+                    # the head are 1x1 convolutions without an activation: merge_preds(head(f)) = (Wp Wh) f + Wp bh is LINEAR in f,
+                    # so it folds into merge_features' weights once, like BatchNorm does:  W' = Wf + Wp Wh,  b' = bf + bp + Wp bh.
+                    # The prediction-merge convolution, its 256-channel output and the residual read of the merge disappear, and
+                    # the heads of the first three stages feed nothing any more (the reference needs them for its training loss).
+                    hd = self.head[t_][s_]
+                    wp = q.weight.detach().float().flatten(1)                  # (K, 50)
+                    wh = hd.weight.detach().float().flatten(1)                 # (50, C)
+                    f.weight = nn.Parameter((f.weight.detach().float().flatten(1) + wp @ wh).view_as(f.weight), requires_grad=False)
+                    f.bias = nn.Parameter(f.bias.detach().float() + wp @ hd.bias.detach().float(), requires_grad=False)
                 # the heads hand over a 64-channel tensor (50 + 14 exact zeros): the prediction-merge convolution reads it
                 # as it is, through a weight whose input channels 50..63 are zero (no copy of the [:, :50] view)
                 wq = torch.zeros((q.weight.shape[0], 64, 1, 1), dtype=q.weight.dtype)
@@ -968,10 +986,15 @@ class FusedIMHN(nn.Module):
             # feats[s] stays a (feature map, SE gains) pair: its consumers -- the head and the merge convolution, both 1x1 --
             # multiply while they read
             feats = [self.feat[t][s](hg[s], fold=True) for s in scales]
-            preds = [self.head[t][s](feats[s]) for s in scales]
-            seen.append(preds[0])
+            if last or stage_preds or not self.folded_merge:
+                preds = [self.head[t][s](feats[s]) for s in (scales if not self.folded_merge else range(1))]
+                seen.append(preds[0])
             if last:
                 return seen if stage_preds else preds[0]
+            if self.folded_merge:   # merge_preds(head(.)) lives inside merge_features' weights: no head, no prediction merge
+                c0, x, x_pooled = self.mfeat[t][0].forward_dual(feats[0], None, x, want_pool=True)
+                caches = [c0] + [self.mfeat[t][s](feats[s]) for s in scales if s > 0]
+                continue
             # cache_s = merge_feat(feat_s) + merge_pred(pred_s); x + cache_0 leaves the scale-0 convolution as a second output
             mp = [self._merge_pred(t, s, preds[s]) for s in scales]
             c0, x, x_pooled = self.mfeat[t][0].forward_dual(feats[0], mp[0], x, want_pool=True)

@@ -148,7 +148,7 @@ def test_streaming_pointwise_convolution_matches_torch(shape):
     for use_scale in ([False, True] if hw % 64 == 0 else [False]):
         xin = (x * sc[:, :, None, None]) if use_scale else x          # the fp16 tensor the separate SE pass would have written
         conv = F.conv2d(xin.float(), wt.float(), b.float())
-        for mode, slope in [(0, 0.01), (1, 0.01), (2, 0.01), (0, 1.0), (4, 1.0)]:
+        for mode, slope in [(0, 0.01), (1, 0.01), (2, 0.01), (0, 1.0), (4, 1.0), (5, 0.01)]:
             ref = conv + ex.float() if mode in (1, 4) else conv
             ref = F.leaky_relu(ref, slope) if slope != 1.0 else ref
             ref = ref + ex.float() if mode == 2 else ref
@@ -156,14 +156,14 @@ def test_streaming_pointwise_convolution_matches_torch(shape):
             y = wide[:, 32:32 + co]                                    # a channel slice: pixel stride co + 64
             y2 = torch.full((n, co, h, w), float("nan"), dtype=torch.float16, device="cuda").contiguous(memory_format=torch.channels_last)
             rc = L.pp_pw_f16(vp(x.data_ptr()), vp(sc.data_ptr()) if use_scale else None, vp(wt.data_ptr()), vp(b.data_ptr()),
-                             vp(ex.data_ptr()) if mode else None, vp(ex2.data_ptr()) if mode == 4 else None, vp(y.data_ptr()),
-                             vp(y2.data_ptr()) if mode == 4 else None, m, hw, ci, co, co + 64, mode, slope, st)
+                             vp(ex.data_ptr()) if mode in (1, 2, 4) else None, vp(ex2.data_ptr()) if mode >= 4 else None, vp(y.data_ptr()),
+                             vp(y2.data_ptr()) if mode >= 4 else None, m, hw, ci, co, co + 64, mode, slope, st)
             assert rc == 0, (shape, mode, rc)
             torch.cuda.synchronize()
             assert torch.isfinite(y).all() and torch.isnan(wide[:, :32]).all() and torch.isnan(wide[:, 32 + co:]).all()
             err = (y.float() - ref).abs().max().item()
             assert err <= 2e-3 * max(1.0, ref.abs().max().item()), (shape, use_scale, mode, err)
-            if mode == 4:
+            if mode >= 4:
                 assert torch.equal(y2, (y.float() + ex2.float()).half())   # the exact sum of the two binary16 tensors, rounded once
     assert L.pp_pw_f16(vp(x.data_ptr()), None, vp(wt.data_ptr()), vp(b.data_ptr()), None, None, vp(x.data_ptr()), None, m, hw, 96, co,
                        co, 0, 0.01, st) == -6                            # an input width the kernel has no instance for
@@ -218,6 +218,27 @@ def test_halo_kernel_emits_the_channel_sums_of_its_output(shape):
     assert torch.equal(y0, y1) and torch.isfinite(ws).all()
     want = y1.float().mean(dim=(2, 3))
     assert (mean.float() - want).abs().max().item() <= 1e-3 * max(1.0, want.abs().max().item())
+
+
+def test_folded_prediction_merge_keeps_every_stage(monkeypatch=None):
+    """merge_preds(head(f)) folded into merge_features' weights (W' = Wf + Wp Wh, b' = bf + bp + Wp bh; models/posenet.py:116-117)
+    against the unfolded model (heads + prediction-merge convolutions computed at every stage): every stage's prediction within
+    fp16 noise of the other form (the unfolded form rounds the intermediate predictions to binary16, the folded one does not)."""
+    from posepaf import fused_model as fm
+    x = torch.from_numpy(np.random.default_rng(13).random((2, 128, 128, 3), dtype=np.float32)).cuda().half()
+    outs = []
+    for folded in (True, False):
+        fm.USE_FOLDED_MERGE = folded
+        try:
+            model = fm.build_inference_model(torch.device("cuda"), fused=True)
+        finally:
+            fm.USE_FOLDED_MERGE = True
+        assert model.folded_merge == folded
+        with torch.no_grad():
+            outs.append([o.float() for o in model(x, stage_preds=True)])
+    for t, (a, b) in enumerate(zip(*outs)):
+        assert a.shape == b.shape == (2, 50, 32, 32)
+        assert (a - b).abs().max().item() <= 0.01 * b.abs().max().item(), t
 
 
 def test_se_gains_folded_into_the_consumers_keep_the_model_output():
