@@ -1010,6 +1010,8 @@ struct PwParams {
     ConvParams e;          // bias, extra, extra2, y, y2, K (= C_out), ldy, mode, slope: the shared epilogue's view
     long M;                // pixels
     int Kin, hw, n_per_wg; // input channels, pixels per image (scale index), output channels per workgroup
+    const _Float16 *x2;    // NULL, or a SECOND input tensor whose channels continue the K axis after x's: y = act(W [x ; x2] + b ...) --
+    int kt1;               // a residual block's last 1x1 and its 1x1 skip convolution as ONE product (k-steps of 32 taken from x: kt1)
     _Float16 *pool;        // NULL, or the 2x2 max-pool of the produced tensor (m / 4 pixels x C_out): groups are then 2-row blocks
     int W;                 // pixels per image row (pool mode)
 };
@@ -1050,9 +1052,11 @@ __global__ __launch_bounds__(512) void k_pw(const PwParams p) {
 #pragma unroll
         for (int i = 0; i < PT; i++) {
             const long m = tile_m(i) + pl;
-            const _Float16 *row = p.x + (m < p.M ? m : 0) * (KT * 32) + g * 8;
+            const long mm = m < p.M ? m : 0;
+            const _Float16 *row = p.x + mm * (p.kt1 * 32) + g * 8;
+            const _Float16 *row2 = p.x2 ? p.x2 + mm * ((KT - p.kt1) * 32) + g * 8 - p.kt1 * 32 : row;   // k-step t >= kt1: row2 + 32 t
 #pragma unroll
-            for (int t = 0; t < KT; t++) xf[i][t] = *reinterpret_cast<const half8_t *>(row + t * 32);
+            for (int t = 0; t < KT; t++) xf[i][t] = *reinterpret_cast<const half8_t *>((t < p.kt1 ? row : row2) + t * 32);
         }
         if (p.scale) {   // the SE gains of this group's image (a group never straddles two images: hw % 64 == 0 is asked of the caller)
             const _Float16 *sc = p.scale + (m0 / p.hw) * (KT * 32) + g * 8;
@@ -1260,7 +1264,8 @@ PP_API int pp_pw_supported(int c_in, int c_out) {
     return ((c_in == 64 || c_in == 128 || c_in == 192 || c_in == 256 || c_in == 384 || c_in == 512) && c_out % 64 == 0 && c_out >= 64) ? 1 : 0;
 }
 static int pw_run(const void *x, const void *scale, const void *w, const void *bias, const void *extra, const void *extra2, void *y,
-                  void *y2, long m, int hw, int c_in, int c_out, int ldy, int extra_mode, float slope, void *pool, int width, void *stream);
+                  void *y2, long m, int hw, int c_in, int c_out, int ldy, int extra_mode, float slope, void *pool, int width, void *stream,
+                  const void *x2 = nullptr, int c_in2 = 0);
 
 PP_API int pp_pw_f16(const void *x, const void *scale, const void *w, const void *bias, const void *extra, const void *extra2, void *y,
                      void *y2, long m, int hw, int c_in, int c_out, int ldy, int extra_mode, float slope, void *stream) {
@@ -1277,8 +1282,20 @@ PP_API int pp_pw_pool_f16(const void *x, const void *scale, const void *w, const
     return pw_run(x, scale, w, bias, extra, extra2, y, y2, m, hw, c_in, c_out, ldy, extra_mode, slope, pool_out, width, stream);
 }
 
+// [x ; x2]: y = act(W [x ; x2] + bias ...), W: (c_out, c_in + c_in2) -- e.g. a residual block's last 1x1 convolution and its 1x1 skip
+// convolution (models/layers_transposed.py:12-48: out = conv3(t) + skip(x)) as one product, the skip's output never materialised.
+// pool_out / width as pp_pw_pool_f16 (NULL / 0: none).  c_in, c_in2 multiples of 32 with a supported sum.
+PP_API int pp_pw_cat_f16(const void *x, const void *x2, const void *w, const void *bias, const void *extra, void *y, void *pool_out, long m,
+                         int hw, int width, int c_in, int c_in2, int c_out, int ldy, int extra_mode, float slope, void *stream) {
+    if (!x2 || c_in <= 0 || c_in2 <= 0 || (c_in & 31) || (c_in2 & 31) || (reinterpret_cast<uintptr_t>(x2) & 15) || extra_mode > 2) return PP_ERR_BAD_ARG;
+    if (pool_out && (width <= 0 || hw % width || ((hw / width) & 1) || width % (c_in + c_in2 == 64 ? 64 : 32) || m % hw)) return PP_ERR_UNSUPPORTED;
+    return pw_run(x, nullptr, w, bias, extra, nullptr, y, nullptr, m, hw, c_in + c_in2, c_out, ldy, extra_mode, slope, pool_out,
+                  pool_out ? width : 0, stream, x2, c_in2);
+}
+
 static int pw_run(const void *x, const void *scale, const void *w, const void *bias, const void *extra, const void *extra2, void *y,
-                  void *y2, long m, int hw, int c_in, int c_out, int ldy, int extra_mode, float slope, void *pool, int width, void *stream) {
+                  void *y2, long m, int hw, int c_in, int c_out, int ldy, int extra_mode, float slope, void *pool, int width, void *stream,
+                  const void *x2, int c_in2) {
     // extra_mode 5 (this kernel only): the second output y2 = y + extra2 WITHOUT a tensor added before the activation
     if (!x || !w || !bias || !y || m <= 0 || hw <= 0 || ldy < c_out || extra_mode < 0 || extra_mode == 3 || extra_mode > 5 ||
         (extra_mode != 0 && extra_mode != 5) != (extra != nullptr) || (extra_mode >= 4) != (extra2 != nullptr) ||
@@ -1302,6 +1319,7 @@ static int pw_run(const void *x, const void *scale, const void *w, const void *b
     p.e.K = c_out, p.e.ldy = ldy, p.e.mode = extra_mode, p.e.slope = slope;
     p.M = m, p.Kin = c_in, p.hw = hw;
     p.pool = static_cast<_Float16 *>(pool), p.W = width;
+    p.x2 = static_cast<const _Float16 *>(x2), p.kt1 = (c_in - c_in2) / 32;   // c_in is the TOTAL here
     // output channels per workgroup: all of them when their weights fit LDS (144 KiB), else the fewest equal splits that do
     int n_split = 1;
     while ((c_out / n_split) * c_in * 2 > 144 * 1024 || c_out % n_split || (c_out / n_split) % 64) {

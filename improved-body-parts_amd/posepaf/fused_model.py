@@ -43,6 +43,7 @@ USE_SUM_FUSION = True       # the SE block's channel sums leave the 3x3 kernel t
 USE_SLICE_OUTPUT = True     # the backbone's concatenation is written in place by its two producers
 USE_COLLAPSED_UP2 = True    # conv3x3(upsample2(x)) as four 2x2 convolutions of x (2.25x fewer multiply-adds)
 USE_FOLDED_MERGE = True     # merge_preds(head(f)) is linear in f: folded into merge_features' weights at load time
+USE_CAT_SKIP = True         # a residual block's last 1x1 and its 1x1 skip convolution as one product over [t ; x]
 USE_POOL_FUSION = True      # the hourglass' 2x2 max-pools leave the 1x1 kernel that produces their input as a second output
 _conv_choice: dict = {}   # shape key -> tile configuration id, or -1 = MIOpen convolution + k_bias_act pass
 _conv_timing: dict = {}   # shape key -> {"miopen": ms, cfg: ms, ...} measured by the autotune (diagnostics)
@@ -845,13 +846,70 @@ class FResidual(nn.Module):
             self.c3.bias = nn.Parameter(self.c3.bias + self.skip.bias, requires_grad=False)
 
     def forward(self, x, out=None):
+        if self.skip is not None and out is None:
+            y = self._cat(x, False)
+            if y is not None:
+                return y[0]
         res = self.skip.conv_only(x) if self.skip is not None else x
         return self.c3(self.c2(self.c1(x)), res, out=out)
 
     def forward_pool(self, x):
         """-> (block output, its 2x2 max-pool): the pooled tensor leaves the block's last 1x1 convolution as a second output"""
+        if self.skip is not None:
+            y = self._cat(x, True)
+            if y is not None:
+                return y
         res = self.skip.conv_only(x) if self.skip is not None else x
         return self.c3.forward_pool(self.c2(self.c1(x)), res)
+
+    def _cat(self, x, want_pool):
+        """conv3(t) + skip(x) as ONE product over the concatenated channels [t ; x] (pp_pw_cat_f16) when both weight matrices fit
+        the streaming kernel's LDS in one piece (otherwise the input would be read once per output-channel split and nothing is
+        gained); timed once per shape against the unfused form.  -> (y, pooled or None), or None."""
+        from . import _lib
+        if not (USE_PW and USE_CAT_SKIP and USE_OWN_CONV and x.is_cuda and x.dtype == torch.float16):
+            return None
+        k, c1 = self.c3.weight.shape[:2]
+        c2 = self.skip.weight.shape[1]
+        n, _, h, w = x.shape
+        if (tuple(self.skip.weight.shape[2:]) != (1, 1) or self.skip.stride != (1, 1) or k * (c1 + c2) * 2 > 144 * 1024
+                or not _lib.load().pp_pw_supported(c1 + c2, k) or c1 % 32 or c2 % 32):
+            return None
+        pool_ok = want_pool and USE_POOL_FUSION and h % 2 == 0 and w % (64 if c1 + c2 == 64 else 32) == 0
+        key = ("cat", n, c1, c2, h, w, k, bool(self.c3.act), pool_ok)
+        if getattr(self, "_wcat", None) is None or self._wcat.device != x.device:
+            self._wcat = torch.cat([self.c3.weight.detach().flatten(1), self.skip.weight.detach().flatten(1)], dim=1).contiguous()
+
+        def separate():
+            res = self.skip.conv_only(x)
+            t = self.c2(self.c1(x))
+            return self.c3.forward_pool(t, res) if want_pool else (self.c3(t, res), None)
+
+        def fused():
+            t = _cl(self.c2(self.c1(x)))
+            xx = _cl(x)
+            y = torch.empty((n, k, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            pooled = torch.empty((n, k, h // 2, w // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last) if pool_ok else None
+            rc = _lib.load().pp_pw_cat_f16(_ptr(t), _ptr(xx), _ptr(self._wcat), _ptr(self.c3.bias), None, _ptr(y), _ptr(pooled), n * h * w,
+                                           h * w, w if pool_ok else 0, c1, c2, k, k, 0, LEAK if self.c3.act else 1.0, _stream(x))
+            if rc != 0:
+                return None
+            return y, (pooled if pool_ok else (maxpool2(y) if want_pool else None))
+
+        choice = _conv_choice.get(key)
+        if choice is None:
+            if torch.cuda.is_current_stream_capturing():
+                return None
+            separate()
+            if fused() is None:
+                choice = 0
+            else:
+                t_sep, t_fused = _timed(separate), _timed(fused)
+                _conv_timing[key] = {"separate": t_sep, "fused": t_fused}
+                choice = 1 if t_fused < t_sep else 0
+            _conv_choice[key] = choice
+            _note(key, choice)
+        return fused() if choice else None
 
 
 class FHourglass(nn.Module):

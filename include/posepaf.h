@@ -256,6 +256,12 @@ PP_API int pp_pw_pool_f16(const void *x, const void *scale, const void *w, const
                           void *y, void *y2, void *pool_out, long m, int hw, int width, int c_in, int c_out, int ldy, int extra_mode,
                           float slope, void *stream);
 
+/* pp_pw_f16 on TWO inputs whose channels continue each other along K: y = act(W [x ; x2] + bias (+ extra)), W: (c_out, c_in + c_in2).
+ * A residual block's last 1x1 convolution and its 1x1 skip convolution (models/layers_transposed.py:12-48: conv3(t) + skip(x)) are one
+ * product this way; the skip's output is never written.  pool_out (NULL: none) / width as pp_pw_pool_f16. */
+PP_API int pp_pw_cat_f16(const void *x, const void *x2, const void *w, const void *bias, const void *extra, void *y, void *pool_out, long m,
+                         int hw, int width, int c_in, int c_in2, int c_out, int ldy, int extra_mode, float slope, void *stream);
+
 /* A1, the stem (models/layers_transposed.py:78-87 Backbone.conv1 + bn1 + LeakyReLU): y = leaky(conv(x, w, 7x7, stride 2, padding 3)
  * + bias) in one HBM-bound pass.  x: DEVICE (n, h, w, 3) NHWC fp16, h even, w % 4 == 0; w_prepared: DEVICE (64, 192) fp16,
  * w_prepared[k][(r * 8 + s1) * 3 + c] = weight[k][c][r][s1 - 1] (zeros for s1 = 0 and past 168); bias fp16[64];

@@ -220,6 +220,36 @@ def test_halo_kernel_emits_the_channel_sums_of_its_output(shape):
     assert (mean.float() - want).abs().max().item() <= 1e-3 * max(1.0, want.abs().max().item())
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 64, 64, 64, 128), (1, 16, 32, 128, 64, 256), (3, 6, 10, 64, 192, 128)])
+def test_two_input_pointwise_convolution_matches_the_sum_of_two(shape):
+    """pp_pw_cat_f16: act(W [x ; x2] + b) == act(conv1x1(x, W[:, :c1]) + conv1x1(x2, W[:, c1:]) + b) -- a residual block's last 1x1 and
+    its skip convolution as one product (models/layers_transposed.py:12-48) -- incl. the pooled output."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from posepaf import _lib
+    L = _lib.load()
+    n, h, w, c1, c2, co = shape
+    g = torch.Generator(device="cpu").manual_seed(71)
+    x1 = torch.randn(n, c1, h, w, generator=g).cuda().half().contiguous(memory_format=torch.channels_last)
+    x2 = torch.randn(n, c2, h, w, generator=g).cuda().half().contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(co, c1 + c2, generator=g) / (c1 + c2) ** 0.5).cuda().half().contiguous()
+    b = torch.randn(co, generator=g).cuda().half()
+    ref = F.leaky_relu(F.conv2d(x1.float(), wt[:, :c1].float()[:, :, None, None]) + F.conv2d(x2.float(), wt[:, c1:].float()[:, :, None, None])
+                       + b.float()[None, :, None, None], 0.01)
+    vp = C.c_void_p
+    st = vp(torch.cuda.current_stream().cuda_stream)
+    pool_ok = h % 2 == 0 and w % (64 if c1 + c2 == 64 else 32) == 0
+    y = torch.full((n, co, h, w), float("nan"), dtype=torch.float16, device="cuda").contiguous(memory_format=torch.channels_last)
+    pooled = torch.full((n, co, h // 2, w // 2), float("nan"), dtype=torch.float16, device="cuda").contiguous(memory_format=torch.channels_last)
+    rc = L.pp_pw_cat_f16(vp(x1.data_ptr()), vp(x2.data_ptr()), vp(wt.data_ptr()), vp(b.data_ptr()), None, vp(y.data_ptr()),
+                         vp(pooled.data_ptr()) if pool_ok else None, n * h * w, h * w, w if pool_ok else 0, c1, c2, co, co, 0, 0.01, st)
+    assert rc == 0, (shape, rc)
+    torch.cuda.synchronize()
+    assert (y.float() - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
+    if pool_ok:
+        assert torch.equal(pooled, F.max_pool2d(y, 2, 2))
+
+
 def test_folded_prediction_merge_keeps_every_stage(monkeypatch=None):
     """merge_preds(head(f)) folded into merge_features' weights (W' = Wf + Wp Wh, b' = bf + bp + Wp bh; models/posenet.py:116-117)
     against the unfolded model (heads + prediction-merge convolutions computed at every stage): every stage's prediction within
