@@ -1261,7 +1261,7 @@ extern "C" {
 // y2: DEVICE (m, c_out) or NULL; y: DEVICE, pixel stride ldy >= c_out.  extra_mode as pp_conv_own_ex_f16 (0, 1, 2, 4).
 // c_in in {64, 128, 192, 256, 384, 512}, c_out % 64 == 0, hw % 32 == 0 when scale is given; PP_ERR_UNSUPPORTED otherwise.
 PP_API int pp_pw_supported(int c_in, int c_out) {
-    return ((c_in == 64 || c_in == 128 || c_in == 192 || c_in == 256 || c_in == 384 || c_in == 512) && c_out % 64 == 0 && c_out >= 64) ? 1 : 0;
+    return ((c_in == 64 || c_in == 128 || c_in == 192 || c_in == 256 || c_in == 384 || c_in == 448 || c_in == 512) && c_out % 64 == 0 && c_out >= 64) ? 1 : 0;
 }
 static int pw_run(const void *x, const void *scale, const void *w, const void *bias, const void *extra, const void *extra2, void *y,
                   void *y2, long m, int hw, int c_in, int c_out, int ldy, int extra_mode, float slope, void *pool, int width, void *stream,
@@ -1333,6 +1333,7 @@ static int pw_run(const void *x, const void *scale, const void *w, const void *b
         case 6: return launch_pw_inst<6>(p, n_split, st);
         case 8: return launch_pw_inst<8>(p, n_split, st);
         case 12: return launch_pw_inst<12>(p, n_split, st);
+        case 14: return launch_pw_inst<14>(p, n_split, st);   // 192 + 256: the [t ; x] input of the first hourglass level's residual blocks
         case 16: return launch_pw_inst<16>(p, n_split, st);
         default: return PP_ERR_UNSUPPORTED;
     }
