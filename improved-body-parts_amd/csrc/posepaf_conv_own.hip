@@ -229,8 +229,8 @@ __device__ __forceinline__ void epilogue_preloaded(const float4_t (&acc)[PT][CT]
                 keep[i] = (MODE == 4 || MODE == 5) ? out2 : out;
             }
         }
-        if (POOL) {
-            constexpr int CB = PT / 2;
+        if (POOL && PT >= 2) {
+            constexpr int CB = PT >= 2 ? PT / 2 : 1;
 #pragma unroll
             for (int cb = 0; cb < CB; cb++) {
                 const half8_t vert = __builtin_elementwise_max(keep[cb], keep[CB + cb]);
@@ -1036,7 +1036,7 @@ __global__ __launch_bounds__(512) void k_pw(const PwParams p) {
     const int wfrag = (lane & 15) * 64 + (((lane >> 4) * 16) ^ (((lane & 15) >> 3) << 5));
     const int g = lane >> 4, pl = lane & 15;
     constexpr int GP = PT * 16;   // pixels per group
-    constexpr int CB = PT / 2;    // pool mode: 16-pixel column blocks per group (the group is 2 rows x 16 CB columns)
+    constexpr int CB = PT >= 2 ? PT / 2 : 1;   // pool mode (PT >= 2): 16-pixel column blocks per group (the group is 2 rows x 16 CB columns)
     const bool pooling = p.pool != nullptr;
     const long groups = (p.M + GP - 1) / GP;
     const int cblocks = pooling ? p.W / (16 * CB) : 1;   // groups per row pair
@@ -1120,8 +1120,11 @@ __global__ __launch_bounds__(512) void k_pw(const PwParams p) {
     }
 }
 
-template <int KT, int PT = (KT <= 2 ? 4 : 2)>
+// pixels per group: 64 for the narrow inputs, 32 up to 512 channels, 16 beyond (all K of a group lives in registers: 32-pixel groups
+// of 640 / 704 channels would spill 70-100 registers)
+template <int KT, int PT = (KT <= 2 ? 4 : (KT <= 16 ? 2 : 1))>
 int launch_pw_inst(const PwParams &p, int n_split, hipStream_t st) {
+    if (PT == 1 && p.pool) return PP_ERR_UNSUPPORTED;   // a 16-pixel group has no 2-row form
     const int lds = p.n_per_wg * KT * 64;   // n_per_wg rows x (KT * 32) halves
     static const int inst = g_inst_count.fetch_add(1);
     if (const int rc = ensure_attr(reinterpret_cast<const void *>(&k_pw<KT, PT>), lds, inst, st)) return rc;
@@ -1261,7 +1264,7 @@ extern "C" {
 // y2: DEVICE (m, c_out) or NULL; y: DEVICE, pixel stride ldy >= c_out.  extra_mode as pp_conv_own_ex_f16 (0, 1, 2, 4).
 // c_in in {64, 128, 192, 256, 384, 512}, c_out % 64 == 0, hw % 32 == 0 when scale is given; PP_ERR_UNSUPPORTED otherwise.
 PP_API int pp_pw_supported(int c_in, int c_out) {
-    return ((c_in == 64 || c_in == 128 || c_in == 192 || c_in == 256 || c_in == 384 || c_in == 448 || c_in == 512) && c_out % 64 == 0 && c_out >= 64) ? 1 : 0;
+    return ((c_in == 64 || c_in == 128 || c_in == 192 || c_in == 256 || c_in == 384 || c_in == 448 || c_in == 512 || c_in == 640 || c_in == 704) && c_out % 64 == 0 && c_out >= 64) ? 1 : 0;
 }
 static int pw_run(const void *x, const void *scale, const void *w, const void *bias, const void *extra, const void *extra2, void *y,
                   void *y2, long m, int hw, int c_in, int c_out, int ldy, int extra_mode, float slope, void *pool, int width, void *stream,
@@ -1335,6 +1338,8 @@ static int pw_run(const void *x, const void *scale, const void *w, const void *b
         case 12: return launch_pw_inst<12>(p, n_split, st);
         case 14: return launch_pw_inst<14>(p, n_split, st);   // 192 + 256: the [t ; x] input of the first hourglass level's residual blocks
         case 16: return launch_pw_inst<16>(p, n_split, st);
+        case 20: return launch_pw_inst<20>(p, n_split, st);   // 256 + 384, 320 + ... : the second hourglass level's [t ; x]
+        case 22: return launch_pw_inst<22>(p, n_split, st);
         default: return PP_ERR_UNSUPPORTED;
     }
 }

@@ -877,7 +877,8 @@ class FResidual(nn.Module):
         if (tuple(self.skip.weight.shape[2:]) != (1, 1) or self.skip.stride != (1, 1)
                 or not _lib.load().pp_pw_supported(c1 + c2, k) or c1 % 32 or c2 % 32):
             return None
-        pool_ok = want_pool and USE_POOL_FUSION and h % 2 == 0 and w % (64 if c1 + c2 == 64 else 32) == 0
+        # (beyond 512 input channels the kernel works on 16-pixel groups, which have no 2-row form to pool)
+        pool_ok = want_pool and USE_POOL_FUSION and h % 2 == 0 and w % (64 if c1 + c2 == 64 else 32) == 0 and c1 + c2 <= 512
         key = ("cat", n, c1, c2, h, w, k, bool(self.c3.act), pool_ok)
         if getattr(self, "_wcat", None) is None or self._wcat.device != x.device:
             self._wcat = torch.cat([self.c3.weight.detach().flatten(1), self.skip.weight.detach().flatten(1)], dim=1).contiguous()

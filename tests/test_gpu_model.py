@@ -220,7 +220,8 @@ def test_halo_kernel_emits_the_channel_sums_of_its_output(shape):
     assert (mean.float() - want).abs().max().item() <= 1e-3 * max(1.0, want.abs().max().item())
 
 
-@pytest.mark.parametrize("shape", [(2, 8, 64, 64, 64, 128), (1, 16, 32, 128, 64, 256), (3, 6, 10, 64, 192, 128)])
+@pytest.mark.parametrize("shape", [(2, 8, 64, 64, 64, 128), (1, 16, 32, 128, 64, 256), (3, 6, 10, 64, 192, 128),
+                                   (2, 16, 32, 192, 256, 384), (2, 8, 32, 256, 384, 512), (1, 16, 16, 320, 384, 640)])
 def test_two_input_pointwise_convolution_matches_the_sum_of_two(shape):
     """pp_pw_cat_f16: act(W [x ; x2] + b) == act(conv1x1(x, W[:, :c1]) + conv1x1(x2, W[:, c1:]) + b) -- a residual block's last 1x1 and
     its skip convolution as one product (models/layers_transposed.py:12-48) -- incl. the pooled output."""
@@ -238,7 +239,7 @@ def test_two_input_pointwise_convolution_matches_the_sum_of_two(shape):
                        + b.float()[None, :, None, None], 0.01)
     vp = C.c_void_p
     st = vp(torch.cuda.current_stream().cuda_stream)
-    pool_ok = h % 2 == 0 and w % (64 if c1 + c2 == 64 else 32) == 0
+    pool_ok = h % 2 == 0 and w % (64 if c1 + c2 == 64 else 32) == 0 and c1 + c2 <= 512   # (16-pixel groups beyond: no pooled output)
     y = torch.full((n, co, h, w), float("nan"), dtype=torch.float16, device="cuda").contiguous(memory_format=torch.channels_last)
     pooled = torch.full((n, co, h // 2, w // 2), float("nan"), dtype=torch.float16, device="cuda").contiguous(memory_format=torch.channels_last)
     rc = L.pp_pw_cat_f16(vp(x1.data_ptr()), vp(x2.data_ptr()), vp(wt.data_ptr()), vp(b.data_ptr()), None, vp(y.data_ptr()),

@@ -23,7 +23,7 @@ torch.cuda.synchronize()
 rows = []
 up2 = {k_: v for k_, v in fm._conv_timing.items() if k_[0] == "up2"}   # upsample -> 3x3 -> add(s): separate launches vs one (forward_up2)
 for key, times in fm._conv_timing.items():
-    if key[0] in ("up2", "dual", "pool", "mean"):
+    if isinstance(key[0], str):   # fusion decisions ("up2", "dual", "pool", "mean", "cat"): listed below
         continue
     n, c, h, w, k, r, pad, dil, mode, act = key[:10]   # (+ ("slice", ldx, ldy) for the in-place halves of the concatenation)
     calls = fm._conv_calls.get(key, 0)
@@ -58,3 +58,7 @@ print("convolution + second output (y, y + other): separate add vs one launch pe
 for key, t in fm._conv_timing.items():
     if key[0] == "dual":
         print(" ", key[1:], {k_: round(v, 3) for k_, v in t.items()}, "chosen", fm._conv_choice[key] or "separate")
+print("last 1x1 + 1x1 skip of a residual block as one product over [t ; x]: separate vs fused, ms")
+for key, t in fm._conv_timing.items():
+    if key[0] == "cat":
+        print(" ", key[1:], {k_: round(v, 3) for k_, v in t.items()}, "chosen", "fused" if fm._conv_choice[key] else "separate")
