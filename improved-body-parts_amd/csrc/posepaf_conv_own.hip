@@ -838,7 +838,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
 // reads out-of-image taps from, the CU count of the persistent grid, and which kernel instances have had their dynamic-LDS
 // attribute raised on that device.  Indexed by hipGetDevice(); initialisation allocates, so it refuses to run inside a stream
 // capture (PP_ERR_UNSUPPORTED: call the entry point once eagerly first, as every warm-up does).
-constexpr int kMaxDevices = 32, kMaxInst = 64;
+constexpr int kMaxDevices = 32, kMaxInst = 192;
 struct DevState {
     void *zero = nullptr;
     int ncu = 0;
@@ -1018,7 +1018,11 @@ struct PwParams {
 
 // PT: 16-pixel tiles per wave and group (2: 32 pixels; 4: 64 pixels for the narrow inputs, whose groups are otherwise too small
 // to pay for a group's fixed cost)
-template <int KT, int PT>
+// EX: what the epilogue adds -- 0: nothing (mode 0), 1: `extra` (modes 1, 2), 2: the second output (modes 4, 5); POOL: the pooled
+// output.  Compile-time, because a kernel that carries every form holds the registers of the richest one (the preloaded `extra` /
+// `extra2` vectors, the pooled rows): the plain stream then spilled at 64 and at 448 / 512 input channels.  (Forcing 128 registers -- two workgroups per
+// CU -- on the forms that need 130-136 was measured SLOWER, 0.39 against 0.33 ms for 256 -> 128 at 128 x 128 x 128.)
+template <int KT, int PT, int EX, bool POOL>
 __global__ __launch_bounds__(512) void k_pw(const PwParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -1037,7 +1041,7 @@ __global__ __launch_bounds__(512) void k_pw(const PwParams p) {
     const int g = lane >> 4, pl = lane & 15;
     constexpr int GP = PT * 16;   // pixels per group
     constexpr int CB = PT >= 2 ? PT / 2 : 1;   // pool mode (PT >= 2): 16-pixel column blocks per group (the group is 2 rows x 16 CB columns)
-    const bool pooling = p.pool != nullptr;
+    constexpr bool pooling = POOL;
     const long groups = (p.M + GP - 1) / GP;
     const int cblocks = pooling ? p.W / (16 * CB) : 1;   // groups per row pair
     for (long grp = (long)blockIdx.x * 8 + wave; grp < groups; grp += (long)gridDim.x * 8) {
@@ -1085,8 +1089,9 @@ __global__ __launch_bounds__(512) void k_pw(const PwParams p) {
 #pragma unroll
                     for (int jp = 0; jp < 2; jp++) {
                         const long o = mm * p.e.K + n_base + c0 + (2 * jp + odd) * 16 + cbase;
-                        pre[i][jp] = (p.e.mode != 0 && p.e.mode != 5) ? *reinterpret_cast<const half8_t *>(p.e.extra + o) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
-                        pre2[i][jp] = p.e.mode >= 4 ? *reinterpret_cast<const half8_t *>(p.e.extra2 + o) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+                        pre[i][jp] = pre2[i][jp] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+                        if (EX == 1 || (EX == 2 && p.e.mode == 4)) pre[i][jp] = *reinterpret_cast<const half8_t *>(p.e.extra + o);
+                        if (EX == 2) pre2[i][jp] = *reinterpret_cast<const half8_t *>(p.e.extra2 + o);
                     }
                 }
             }
@@ -1104,30 +1109,23 @@ __global__ __launch_bounds__(512) void k_pw(const PwParams p) {
                 const long m = tile_m(i) + pl;
                 return m < p.M ? m : -1;
             };
-            if (pooling) {
-                const long pb = rp * (p.W >> 1) + (long)cbk * CB * 8;   // the group's first pooled pixel
-                if (p.e.mode == 0) epilogue_preloaded<0, PT, 4, true>(acc, p.e, lane, n_base + c0, pix, pre, pre2, p.pool, pb);
-                else if (p.e.mode == 1) epilogue_preloaded<1, PT, 4, true>(acc, p.e, lane, n_base + c0, pix, pre, pre2, p.pool, pb);
-                else if (p.e.mode == 2) epilogue_preloaded<2, PT, 4, true>(acc, p.e, lane, n_base + c0, pix, pre, pre2, p.pool, pb);
-                else if (p.e.mode == 4) epilogue_preloaded<4, PT, 4, true>(acc, p.e, lane, n_base + c0, pix, pre, pre2, p.pool, pb);
-                else epilogue_preloaded<5, PT, 4, true>(acc, p.e, lane, n_base + c0, pix, pre, pre2, p.pool, pb);
-            } else if (p.e.mode == 0) epilogue_preloaded<0, PT, 4, false>(acc, p.e, lane, n_base + c0, pix, pre, pre2);
-            else if (p.e.mode == 1) epilogue_preloaded<1, PT, 4, false>(acc, p.e, lane, n_base + c0, pix, pre, pre2);
-            else if (p.e.mode == 2) epilogue_preloaded<2, PT, 4, false>(acc, p.e, lane, n_base + c0, pix, pre, pre2);
-            else if (p.e.mode == 4) epilogue_preloaded<4, PT, 4, false>(acc, p.e, lane, n_base + c0, pix, pre, pre2);
-            else epilogue_preloaded<5, PT, 4, false>(acc, p.e, lane, n_base + c0, pix, pre, pre2);
+            const long pb = pooling ? rp * (p.W >> 1) + (long)cbk * CB * 8 : 0;   // the group's first pooled pixel
+            if (EX == 0) epilogue_preloaded<0, PT, 4, POOL>(acc, p.e, lane, n_base + c0, pix, pre, pre2, p.pool, pb);
+            else if (EX == 1 && p.e.mode == 1) epilogue_preloaded<1, PT, 4, POOL>(acc, p.e, lane, n_base + c0, pix, pre, pre2, p.pool, pb);
+            else if (EX == 1) epilogue_preloaded<2, PT, 4, POOL>(acc, p.e, lane, n_base + c0, pix, pre, pre2, p.pool, pb);
+            else if (p.e.mode == 4) epilogue_preloaded<4, PT, 4, POOL>(acc, p.e, lane, n_base + c0, pix, pre, pre2, p.pool, pb);
+            else epilogue_preloaded<5, PT, 4, POOL>(acc, p.e, lane, n_base + c0, pix, pre, pre2, p.pool, pb);
         }
     }
 }
 
 // pixels per group: 64 for the narrow inputs, 32 up to 512 channels, 16 beyond (all K of a group lives in registers: 32-pixel groups
 // of 640 / 704 channels would spill 70-100 registers)
-template <int KT, int PT = (KT <= 2 ? 4 : (KT <= 16 ? 2 : 1))>
-int launch_pw_inst(const PwParams &p, int n_split, hipStream_t st) {
-    if (PT == 1 && p.pool) return PP_ERR_UNSUPPORTED;   // a 16-pixel group has no 2-row form
+template <int KT, int PT, int EX, bool POOL>
+int launch_pw_form(const PwParams &p, int n_split, hipStream_t st) {
     const int lds = p.n_per_wg * KT * 64;   // n_per_wg rows x (KT * 32) halves
     static const int inst = g_inst_count.fetch_add(1);
-    if (const int rc = ensure_attr(reinterpret_cast<const void *>(&k_pw<KT, PT>), lds, inst, st)) return rc;
+    if (const int rc = ensure_attr(reinterpret_cast<const void *>(&k_pw<KT, PT, EX, POOL>), lds, inst, st)) return rc;
     DevState *ds = dev_state();
     if (!ds) return PP_ERR_HIP;
     if (ds->ncu == 0) {
@@ -1141,8 +1139,19 @@ int launch_pw_inst(const PwParams &p, int n_split, hipStream_t st) {
     long gx = (long)ds->ncu * per_cu / n_split;
     if (gx < 1) gx = 1;
     if (gx * 8 > groups) gx = (groups + 7) / 8;
-    hipLaunchKernelGGL((k_pw<KT, PT>), dim3((unsigned)gx, (unsigned)n_split), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((k_pw<KT, PT, EX, POOL>), dim3((unsigned)gx, (unsigned)n_split), dim3(512), lds, st, p);
     return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
+}
+template <int KT, int PT = (KT <= 2 ? 4 : (KT <= 16 ? 2 : 1))>
+int launch_pw_inst(const PwParams &p, int n_split, hipStream_t st) {
+    const int ex = p.e.mode == 0 ? 0 : (p.e.mode <= 2 ? 1 : 2);
+    if (p.pool) {
+        if constexpr (PT == 1) return PP_ERR_UNSUPPORTED;   // a 16-pixel group has no 2-row form
+        else return ex == 0 ? launch_pw_form<KT, PT, 0, true>(p, n_split, st)
+                   : ex == 1 ? launch_pw_form<KT, PT, 1, true>(p, n_split, st) : launch_pw_form<KT, PT, 2, true>(p, n_split, st);
+    }
+    return ex == 0 ? launch_pw_form<KT, PT, 0, false>(p, n_split, st)
+         : ex == 1 ? launch_pw_form<KT, PT, 1, false>(p, n_split, st) : launch_pw_form<KT, PT, 2, false>(p, n_split, st);
 }
 
 // ------------------------------------------------------------------------------------------------ the stem: 7x7, stride 2
