@@ -50,6 +50,7 @@ struct ConvParams {
                        // block's squeeze (models/layers_transposed.py:298-303) without a pass of its own over y
     int ldy;           // elements between consecutive pixels of y (K: packed; larger: y is a channel slice of a wider tensor,
                        // e.g. one half of the backbone's concatenation, models/layers_transposed.py:193-195)
+    int ldx = 0;       // the same for x (3x3 halo kernel only); 0: packed (C)
     long M;            // N * Ho * Wo
     int mode;          // 0 none, 1 extra added before the activation, 2 after, 3 extra AND extra2 after (3x3 halo kernel),
                        // 4 = mode 1 plus a SECOND OUTPUT y2 = y + extra2 (every kernel)
@@ -460,6 +461,7 @@ struct HaloParams {
     int HWp, nhalo, npieces;  // halo row length TW + 2, halo pixels, 16-pixel DMA pieces (last one padded)
     int gimg, hrows;          // images per tile and halo rows per image: 1 / TH + 2, or -- maps lower than a tile (16 x 16) -- TH / H
                               // WHOLE images stacked in one tile, each with its own H + 2 halo rows
+    int tps;                  // dilated form: tiles per row class (see D below)
 };
 
 // DIAGNOSTIC (MASK bit 1024): shader clock / 100 MHz reference clock stamps around the main loop of each workgroup's first tile
@@ -469,11 +471,18 @@ __device__ unsigned long long g_conv_clk[8 * 512];
 // upsample convolution (pp_conv_up2_collapsed_f16): the input is the half-resolution tensor, the weights are (K, 2, 2, C) tap sums,
 // only the FOUR taps of the 3x3 neighbourhood that phase sees are walked -- rows PH >> 1 + {0, 1}, columns PH & 1 + {0, 1} of the
 // same halo -- and output pixel (y, x) of the tile lands at (2 y + py, 2 x + px) of a tensor twice the size.
-template <int BN, int MASK, int LGTW, int PH = -1>
+// D: dilation (= padding) of the 3x3 convolution (models/layers_transposed.py:125-157, the backbone's DilatedConv 3, 3, 4, 4, 5, 5).
+// Rows y, y +- D of an image never mix with the rows in between, so the image's rows are taken CLASS BY CLASS (y mod D): a tile is
+// TH rows of ONE class -- real rows y0, y0 + D, y0 + 2 D, ... -- and its halo rows above and below are y0 - D and y0 + TH D:
+// vertically the dilated convolution is the ordinary one on a permuted image.  Horizontally the halo row is TW + 2 D pixels long
+// and the taps read it at column offsets 0, D, 2 D.  Tiles per class: ceil(ceil(H / D) / TH); rows past the image read zeros and
+// store nothing (128 rows: 97 % / 100 % / 91 % of the tile rows are real for D = 3 / 4 / 5).
+template <int BN, int MASK, int LGTW, int PH = -1, int D = 1>
 __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, const HaloParams hp) {
     constexpr int NT = PH < 0 ? 9 : 4;   // taps per channel block
+    static_assert(D == 1 || PH < 0, "the collapsed upsample form has no dilation");
     // The tile geometry is a template parameter: every fragment address is then "lane register + immediate" (see R[][] below).
-    constexpr int TW = 1 << LGTW, HWp = TW + 2, TH = TP / TW;
+    constexpr int TW = 1 << LGTW, HWp = TW + 2 * D, TH = TP / TW;
     constexpr int dbg = MASK;  // ablation switches are COMPILE-TIME (a runtime switch costs a branch per guarded instruction); 0 in production
     constexpr int WN = BN / 64;          // 2
     constexpr int WM = 8 / WN;           // 4
@@ -530,11 +539,16 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
         n_img = (ptile / hp.tiles) * hp.gimg;   // the tile's (first) image
         const int tile = ptile - (ptile / hp.tiles) * hp.tiles;
         t_idx = tile;
-        ty0 = (tile / hp.tiles_x) * TH;
+        if (D == 1) ty0 = (tile / hp.tiles_x) * TH;
+        else {   // row class c = (tile row) / tps, tile t of that class: real rows c + (t TH + 0 .. TH - 1) D
+            const int trow_ = tile / hp.tiles_x, cls = trow_ / hp.tps;
+            ty0 = cls + (trow_ - cls * hp.tps) * TH * D;
+        }
         tx0 = (tile - (tile / hp.tiles_x) * hp.tiles_x) * TW;
         n0 = ctile * BN;
         const int sw_ = p.up ? p.W >> 1 : p.W;                                       // source row length in pixels
-        xb = reinterpret_cast<const char *>(p.x) + (long)n_img * (p.up ? p.H >> 1 : p.H) * sw_ * p.C * 2;   // this image
+        const int ldx = p.ldx ? p.ldx : p.C;                                         // elements between consecutive input pixels
+        xb = reinterpret_cast<const char *>(p.x) + (long)n_img * (p.up ? p.H >> 1 : p.H) * sw_ * ldx * 2;   // this image
         int ln = lane;
         asm volatile("" : "+v"(ln));   // recomputed per tile: hoisted, the per-piece halo coordinates would sit in 20 registers
 #pragma unroll
@@ -544,10 +558,10 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
             const int logical = phys ^ (((phys >> 8) & 1) << 5);
             const int hpix = logical >> 6, chunk = (logical >> 4) & 3;
             const int hy = hpix / HWp, hx = hpix - hy * HWp;
-            const int gi = hy / hp.hrows;                              // image of the tile this halo row belongs to (0 unless stacked)
-            const int iy = ty0 - 1 + (hy - gi * hp.hrows), ix = tx0 - 1 + hx;
+            const int gi = D == 1 ? hy / hp.hrows : 0;                 // image of the tile this halo row belongs to (0 unless stacked)
+            const int iy = D == 1 ? ty0 - 1 + (hy - gi * hp.hrows) : ty0 + (hy - 1) * D, ix = tx0 - D + hx;
             const bool ok = hpix < hp.nhalo && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            hsrc[t] = ok ? (((gi * (p.H >> p.up) + (iy >> p.up)) * sw_ + (ix >> p.up)) * p.C * 2 + chunk * 16)
+            hsrc[t] = ok ? (((gi * (p.H >> p.up) + (iy >> p.up)) * sw_ + (ix >> p.up)) * ldx * 2 + chunk * 16)
                          : (int)0x80000000;   // outside num_records: zeros
         }
         const int b = ln * 16;
@@ -559,7 +573,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
         const unsigned long long aw = reinterpret_cast<unsigned long long>(wb) + (unsigned long long)((long)(n0 + wave * 16) * ((long)NT * p.C * 2));
         bx_lo = __builtin_amdgcn_readfirstlane((int)(unsigned)ax), bx_hi = __builtin_amdgcn_readfirstlane((int)(unsigned)(ax >> 32));
         bw_lo = __builtin_amdgcn_readfirstlane((int)(unsigned)aw), bw_hi = __builtin_amdgcn_readfirstlane((int)(unsigned)(aw >> 32));
-        nx = __builtin_amdgcn_readfirstlane(hp.gimg * (p.up ? p.H >> 1 : p.H) * sw_ * p.C * 2);
+        nx = __builtin_amdgcn_readfirstlane(hp.gimg * (p.up ? p.H >> 1 : p.H) * sw_ * ldx * 2);
         bw_n = __builtin_amdgcn_readfirstlane(n0 + wave * 16 < p.K ? 16 * NT * p.C * 2 : 0);   // bytes of this wave's 16 weight rows
         return true;
     };
@@ -618,7 +632,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     };
     auto xread = [&](auto TAP, auto I, half8_t &dst) {   // pixel fragment of (tap, pixel tile i) from the halo buffer R points to
         constexpr int tap = decltype(TAP)::value, i = decltype(I)::value;
-        constexpr int trow = PH < 0 ? tap / 3 : (PH >> 1) + (tap >> 1), tcol = PH < 0 ? tap % 3 : (PH & 1) + (tap & 1);
+        constexpr int trow = PH < 0 ? tap / 3 : (PH >> 1) + (tap >> 1), tcol = PH < 0 ? D * (tap % 3) : (PH & 1) + (tap & 1);
         constexpr int Cpix = trow * HWp + tcol + ((i * 16) >> LGTW) * HWp + ((i * 16) & (TW - 1));
         constexpr int C = Cpix * 64, k = Cpix & 3, Chi = C & ~255, f = (Chi >> 8) & 1;
         static_assert(Chi < 65536, "16-bit DS offset");
@@ -825,6 +839,10 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
         const int qy = q >> LGTW, qx = q & (TW - 1);
         if (PH >= 0)   // collapsed upsample convolution: this phase's place in the tensor of twice the size (rows counted globally)
             return (2 * ((long)c_img * p.H + c_ty0 + qy) + (PH >> 1)) * (2 * p.W) + 2 * (c_tx0 + qx) + (PH & 1);
+        if (D > 1) {   // tile row qy is real row y0 + qy D of its class; the class may end inside the tile
+            const int ry = c_ty0 + qy * D;
+            return ry < p.H ? ((long)c_img * p.H + ry) * p.W + c_tx0 + qx : -1;
+        }
         return ((long)c_img * p.H + c_ty0 + qy) * p.W + c_tx0 + qx;
     }, !(dbg & 8), p.csum ? p.csum + (((long)c_img * hp.tiles + c_tile) * WM + wm) * p.K : nullptr);
     stamp(4);            // 4: epilogue (issue)
@@ -870,8 +888,9 @@ int ensure_attr(const void *fn, int lds, int inst, hipStream_t st) {
 // geometry of the halo kernel for an image size, or false when the shape is not taken (the implicit-GEMM kernel runs it)
 
 bool halo_geometry(const ConvParams &p, HaloParams &g) {
-    if (p.R != 3 || p.pad != 1 || p.dil != 1 || p.C % 32 || p.K % 64) return false;   // K = 64 mod 128: the last channel tile is half empty
-    if ((long)p.H * p.W * p.C * 2 >= (1L << 31)) return false;   // 32-bit byte offsets inside one image
+    if (p.R != 3 || p.pad != p.dil || p.dil < 1 || p.C % 32 || p.K % 64) return false;   // K = 64 mod 128: the last channel tile is half empty
+    if (p.dil != 1 && (p.dil < 3 || p.dil > 5 || p.up || p.csum)) return false;          // dilated instances: 3, 4, 5 (the backbone's)
+    if ((long)p.H * p.W * (p.ldx ? p.ldx : p.C) * 2 >= (1L << 31)) return false;   // 32-bit byte offsets inside one image
     int tw = 128;   // the widest power-of-two tile (<= 128) that divides the image width: 128, 64 (e.g. W = 192), 32 (96), 16 (48)
     while (tw >= 16 && p.W % tw) tw >>= 1;
     if (tw < 16) return false;
@@ -880,8 +899,17 @@ bool halo_geometry(const ConvParams &p, HaloParams &g) {
     g.TH = th;
     g.lgTW = 0;
     while ((1 << g.lgTW) < tw) g.lgTW++;
-    g.HWp = tw + 2;
-    if (p.H % th == 0) {
+    g.HWp = tw + 2 * p.dil;
+    g.tps = 0;
+    if (p.dil > 1) {   // rows class by class (see k_conv3x3_halo): D classes of ceil(ceil(H / D) / th) tiles each
+        if (tw < 32) return false;   // instances exist for the 128-, 64- and 32-wide tiles
+        g.gimg = 1;
+        g.hrows = th + 2;
+        g.tiles_x = p.W / tw;
+        g.tps = ((p.H + p.dil - 1) / p.dil + th - 1) / th;
+        g.tiles = g.tiles_x * p.dil * g.tps;
+        g.nhalo = (th + 2) * (tw + 2 * p.dil);
+    } else if (p.H % th == 0) {
         g.gimg = 1;
         g.hrows = th + 2;
         g.tiles_x = p.W / tw;
@@ -903,11 +931,11 @@ bool halo_geometry(const ConvParams &p, HaloParams &g) {
 
 
 
-template <int MASK, int LGTW, int PH = -1>
+template <int MASK, int LGTW, int PH = -1, int D = 1>
 int launch_halo_inst(const ConvParams &p, const HaloParams &g, hipStream_t st) {
     const int lds = 2 * 56 * SUB + 6 * (128 * 32 * 2);   // two halo buffers of 56 pieces, weight ring of 6 slices
     static const int inst = g_inst_count.fetch_add(1);
-    if (const int rc = ensure_attr(reinterpret_cast<const void *>(&k_conv3x3_halo<128, MASK, LGTW, PH>), lds, inst, st)) return rc;
+    if (const int rc = ensure_attr(reinterpret_cast<const void *>(&k_conv3x3_halo<128, MASK, LGTW, PH, D>), lds, inst, st)) return rc;
     const unsigned ptiles = (unsigned)((p.N / g.gimg) * g.tiles);
     const unsigned ids = ((ptiles + 7) / 8) * 8 * (unsigned)((p.K + 127) / 128);   // 8 XCD ranges x ceil(ptiles / 8) x channel tiles
     DevState *ds = dev_state();   // persistent grid: one workgroup per CU (160 KiB of LDS each), a multiple of 8
@@ -930,12 +958,26 @@ int launch_halo_inst(const ConvParams &p, const HaloParams &g, hipStream_t st) {
         const float f = 0.5f * (rounds < 32.f ? rounds / 32.f : 1.f);
         q.stagger = grid.x < ids ? (int)(f * (float)(p.C / 32 * (PH < 0 ? 9 : 4)) * 1500.f / 8128.f + 0.5f) : 0;
     }
-    hipLaunchKernelGGL((k_conv3x3_halo<128, MASK, LGTW, PH>), grid, dim3(NTHREADS), lds, st, q, g);
+    hipLaunchKernelGGL((k_conv3x3_halo<128, MASK, LGTW, PH, D>), grid, dim3(NTHREADS), lds, st, q, g);
     return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
+}
+
+template <int D>
+int launch_halo_dilated(const ConvParams &p, const HaloParams &g, hipStream_t st) {
+    switch (g.lgTW) {
+        case 7: return launch_halo_inst<0, 7, -1, D>(p, g, st);
+        case 6: return launch_halo_inst<0, 6, -1, D>(p, g, st);
+        case 5: return launch_halo_inst<0, 5, -1, D>(p, g, st);
+        default: return PP_ERR_UNSUPPORTED;
+    }
 }
 
 template <int MASK>
 int launch_halo_mask(const ConvParams &p, const HaloParams &g, hipStream_t st) {
+    if (p.dil != 1) {
+        if (MASK != 0) return PP_ERR_UNSUPPORTED;
+        return p.dil == 3 ? launch_halo_dilated<3>(p, g, st) : (p.dil == 4 ? launch_halo_dilated<4>(p, g, st) : launch_halo_dilated<5>(p, g, st));
+    }
     if (g.lgTW == 7) return launch_halo_inst<MASK, 7>(p, g, st);
     if (MASK == 0) {   // the ablated instances exist for the 128-wide tile only
         if (g.lgTW == 6) return launch_halo_inst<0, 6>(p, g, st);
@@ -1401,9 +1443,32 @@ PP_API int pp_conv_debug_clock(double *out, int nwg) {
 
 PP_API int pp_conv_own_supported(int c_in, int c_out, int ksize) { return (c_in % 32 == 0 && c_out % 64 == 0 && ksize >= 1 && ksize <= 7) ? 1 : 0; }
 
+static int conv_own_run(const void *x, const void *w, const void *bias, const void *extra, const void *extra2, void *y, void *y2,
+                        int n, int h, int wd, int c_in, int c_out, int ksize, int pad, int dilation, int extra_mode, float slope, int bn,
+                        int upsampled_input, int ldx, int ldy, void *stream);
+
 PP_API int pp_conv_own_ex_f16(const void *x, const void *w, const void *bias, const void *extra, const void *extra2, void *y, void *y2,
                        int n, int h, int wd, int c_in, int c_out, int ksize, int pad, int dilation, int extra_mode, float slope, int bn,
                        int upsampled_input, void *stream) {
+    return conv_own_run(x, w, bias, extra, extra2, y, y2, n, h, wd, c_in, c_out, ksize, pad, dilation, extra_mode, slope, bn,
+                        upsampled_input, c_in, c_out, stream);
+}
+
+// pp_conv_own_f16 on channel SLICES of wider NHWC tensors: ldx / ldy = elements between consecutive pixels of x / y (>= c_in /
+// c_out, multiples of 8).  The 3x3 halo kernel only (bn = 512; pad = dilation = 1, or 3 / 4 / 5): PP_ERR_UNSUPPORTED for the shapes
+// it does not take.  `extra` stays packed (n, h, w, c_out).
+PP_API int pp_conv_own_ld_f16(const void *x, const void *w, const void *bias, const void *extra, void *y, int n, int h, int wd, int c_in,
+                              int c_out, int ksize, int pad, int dilation, int extra_mode, float slope, int bn, int ldx, int ldy,
+                              void *stream) {
+    if (extra_mode > 2 || ldx < c_in || ldy < c_out || ((ldx | ldy) & 7)) return PP_ERR_BAD_ARG;
+    if (bn != 512) return PP_ERR_UNSUPPORTED;
+    return conv_own_run(x, w, bias, extra, nullptr, y, nullptr, n, h, wd, c_in, c_out, ksize, pad, dilation, extra_mode, slope, bn, 0,
+                        ldx, ldy, stream);
+}
+
+static int conv_own_run(const void *x, const void *w, const void *bias, const void *extra, const void *extra2, void *y, void *y2,
+                        int n, int h, int wd, int c_in, int c_out, int ksize, int pad, int dilation, int extra_mode, float slope, int bn,
+                        int upsampled_input, int ldx, int ldy, void *stream) {
     if (!x || !w || !bias || !y || n <= 0 || h <= 0 || wd <= 0 || ksize <= 0 || pad < 0 || dilation <= 0 || extra_mode < 0 ||
         extra_mode > 4 || (extra_mode != 0) != (extra != nullptr) || (extra_mode >= 3) != (extra2 != nullptr) ||
         (extra_mode == 4) != (y2 != nullptr) || (upsampled_input != 0 && upsampled_input != 1) ||
@@ -1437,7 +1502,8 @@ PP_API int pp_conv_own_ex_f16(const void *x, const void *w, const void *bias, co
     p.y2 = static_cast<_Float16 *>(y2);
     p.zero = ds->zero;
     p.N = n; p.H = h; p.W = wd; p.C = c_in; p.K = c_out; p.R = ksize; p.pad = pad; p.dil = dilation; p.Ho = ho; p.Wo = wo;
-    p.ldy = c_out;
+    p.ldy = ldy;
+    p.ldx = ldx;
     p.csum = nullptr;
     p.pad_y = p.pad_x = pad, p.up_out = 0, p.py = p.px = 0;
     p.M = (long)n * ho * wo;
@@ -1454,7 +1520,7 @@ PP_API int pp_conv_own_ex_f16(const void *x, const void *w, const void *bias, co
     if (bn == 0 || bn == 512) {   // 512: the halo-tile 3x3 kernel
         HaloParams g;
         if (halo_geometry(p, g)) return launch_halo(p, g, st);
-        if (bn != 0) return PP_ERR_UNSUPPORTED;
+        if (bn != 0 || ldx != c_in || ldy != c_out) return PP_ERR_UNSUPPORTED;   // (the implicit-GEMM kernel reads packed pixels)
         bn = c_out % 256 == 0 ? 256 : (c_out % 128 == 0 ? 128 : 64);
     }
     switch (bn) {

@@ -339,8 +339,13 @@ class FConv(nn.Module):
     def _fused_launch(self, cfg, x, extra, mode, y):
         from . import _lib
         n, c, h, w = x.shape
+        sliced = x.stride(3) != c or y.stride(3) != self.weight.shape[0]
+        if cfg == 104 and sliced:   # the 3x3 halo kernel takes pixel strides on both sides
+            return _lib.load().pp_conv_own_ld_f16(_ptr(x), _ptr(self.weight), _ptr(self.bias), _ptr(extra), _ptr(y), n, h, w, c,
+                                                  self.weight.shape[0], self.weight.shape[2], self.padding[0], self.dilation[0], mode,
+                                                  LEAK if self.act else 1.0, 512, x.stride(3), y.stride(3), _stream(x))
         if cfg >= 100 and (x.stride(3) != c or (cfg != PW_VARIANT and y.stride(3) != self.weight.shape[0])):
-            return -6   # the hand-written kernels read packed inputs; only the streaming 1x1 kernel writes a channel slice
+            return -6   # the implicit-GEMM kernels read and write packed pixels; the streaming 1x1 kernel writes a channel slice
         if cfg == PW_VARIANT:
             if self.weight.shape[2] != 1 or self.padding[0] != 0:
                 return -6

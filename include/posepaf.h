@@ -214,6 +214,13 @@ PP_API int pp_conv_debug_clock(double *out6, int nwg);
 PP_API int pp_conv_own_f16(const void *x, const void *w, const void *bias, const void *extra, void *y, int n, int h, int wd,
                            int c_in, int c_out, int ksize, int pad, int dilation, int extra_mode, float slope, int bn,
                            void *stream);
+/* The same on channel SLICES of wider NHWC tensors (ldx / ldy = elements between consecutive pixels of x / y, multiples of 8; `extra`
+ * stays packed) -- the backbone's concatenation written and read in place (models/layers_transposed.py:193-195).  The 3x3
+ * halo-tile kernel only (bn = 512): pad = dilation = 1, or the backbone's dilated convolutions pad = dilation = 3 / 4 / 5
+ * (models/layers_transposed.py:125-157, :175-182), whose rows the kernel walks class by class (y mod dilation). */
+PP_API int pp_conv_own_ld_f16(const void *x, const void *w, const void *bias, const void *extra, void *y, int n, int h, int wd,
+                              int c_in, int c_out, int ksize, int pad, int dilation, int extra_mode, float slope, int bn, int ldx,
+                              int ldy, void *stream);
 /* The same with extensions.  For the 3x3 / pad 1 halo-tile kernel (bn = 512 only, PP_ERR_UNSUPPORTED otherwise):
  *  - upsampled_input = 1: x is (n, h/2, wd/2, c_in) and stands for its x2 nearest-neighbour upsample (h, wd even) -- the
  *    `self.upsample(down3)` of models/layers_transposed.py:272 (nn.Upsample, :212) without materialising the upsample;

@@ -555,6 +555,85 @@ def test_halo_tile_3x3_convolution_matches_torch(shape):
 
 
 @pytest.mark.parametrize("shape", [
+    # n, c_in, c_out, h, w, dilation (= padding)
+    (2, 128, 128, 128, 128, 3),   # the backbone's geometry at 512 x 512: 4 x 128 tiles, 3 row classes of 43 / 43 / 42 rows (11 tiles each)
+    (2, 128, 128, 128, 128, 4),   # 4 classes of 32 rows: every tile row is real
+    (1, 128, 128, 128, 128, 5),   # 5 classes of 26 / 26 / 26 / 25 / 25 rows in 7 tiles each
+    (1, 64, 128, 50, 64, 3),      # 8 x 64 tiles, classes of 17 / 17 / 16 rows: the last tile of a class holds one or no real row
+    (3, 32, 192, 37, 96, 5),      # 16 x 32 tiles, three per row band, classes shorter than a tile; C_out = 64 mod 128
+    (1, 64, 64, 7, 32, 4),        # fewer rows than two per class
+    (5, 32, 128, 24, 256, 4),     # two 128-wide tiles per row: the halo crosses the tile border by 4 columns
+])
+def test_dilated_3x3_convolution_on_the_halo_kernel_matches_torch(shape):
+    """pp_conv_own_f16 with bn = 512 and dilation 3 / 4 / 5 (models/layers_transposed.py:125-157, the backbone's DilatedConv
+    stack): the halo kernel walks the image's rows class by class (y mod d) and reads its taps at column offsets 0, d, 2 d of a
+    halo row d pixels wider on each side.  Borders, classes that end inside a tile, every epilogue variant; same tolerance."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from posepaf import _lib
+    L = _lib.load()
+    n, ci, co, h, w, d = shape
+    g = torch.Generator(device="cpu").manual_seed(29)
+    x = torch.randn(n, ci, h, w, generator=g).cuda().half().contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(co, ci, 3, 3, generator=g) / (ci * 9) ** 0.5).cuda().half().contiguous(memory_format=torch.channels_last)
+    b = torch.randn(co, generator=g).cuda().half()
+    ex = torch.randn(n, co, h, w, generator=g).cuda().half().contiguous(memory_format=torch.channels_last)
+    conv = F.conv2d(x.float(), wt.float(), b.float(), 1, d, d)
+    vp = C.c_void_p
+    stream = vp(torch.cuda.current_stream().cuda_stream)
+    for mode, slope in [(0, 0.01), (1, 0.01), (2, 0.01), (0, 1.0)]:
+        ref = conv + ex.float() if mode == 1 else conv
+        ref = F.leaky_relu(ref, slope) if slope != 1.0 else ref
+        ref = ref + ex.float() if mode == 2 else ref
+        for rep in range(2):
+            y = torch.full((n, co, h, w), float("nan"), dtype=torch.float16, device="cuda").contiguous(memory_format=torch.channels_last)
+            rc = L.pp_conv_own_f16(vp(x.data_ptr()), vp(wt.data_ptr()), vp(b.data_ptr()), vp(ex.data_ptr()) if mode else None,
+                                   vp(y.data_ptr()), n, h, w, ci, co, 3, d, d, mode, slope, 512, stream)
+            assert rc == 0, (mode, rc)
+            torch.cuda.synchronize()
+            assert torch.isfinite(y).all(), (shape, mode)     # every pixel written exactly by some tile
+            err = (y.float() - ref).abs().max().item()
+            assert err <= 2e-3 * max(1.0, ref.abs().max().item()), (shape, mode, slope, rep, err)
+    # padding != dilation is not this kernel's
+    y = torch.empty((n, co, h - 2, w - 2), dtype=torch.float16, device="cuda").contiguous(memory_format=torch.channels_last)
+    assert L.pp_conv_own_f16(vp(x.data_ptr()), vp(wt.data_ptr()), vp(b.data_ptr()), None, vp(y.data_ptr()), n, h, w, ci, co, 3, d - 1, d,
+                             0, 0.01, 512, stream) == -6
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 128, 32, 128, 1), (1, 128, 128, 64, 128, 3), (2, 32, 64, 24, 64, 5)])
+def test_halo_kernel_reads_and_writes_channel_slices_in_place(shape):
+    """pp_conv_own_ld_f16: x and y are channel slices of wider NHWC tensors (the backbone's concatenation,
+    models/layers_transposed.py:193-195): same values as the packed call, and not a byte outside the slice is written."""
+    import ctypes as C
+    from posepaf import _lib
+    L = _lib.load()
+    n, ci, co, h, w, d = shape
+    g = torch.Generator(device="cpu").manual_seed(31)
+    xw = torch.randn(n, 40 + ci + 24, h, w, generator=g).cuda().half().contiguous(memory_format=torch.channels_last)
+    x = xw[:, 40:40 + ci]
+    wt = (torch.randn(co, ci, 3, 3, generator=g) / (ci * 9) ** 0.5).cuda().half().contiguous(memory_format=torch.channels_last)
+    b = torch.randn(co, generator=g).cuda().half()
+    ex = torch.randn(n, co, h, w, generator=g).cuda().half().contiguous(memory_format=torch.channels_last)
+    vp = C.c_void_p
+    st = vp(torch.cuda.current_stream().cuda_stream)
+    xp = x.contiguous(memory_format=torch.channels_last)
+    for mode in (0, 1):
+        want = torch.empty((n, co, h, w), dtype=torch.float16, device="cuda").contiguous(memory_format=torch.channels_last)
+        assert L.pp_conv_own_f16(vp(xp.data_ptr()), vp(wt.data_ptr()), vp(b.data_ptr()), vp(ex.data_ptr()) if mode else None,
+                                 vp(want.data_ptr()), n, h, w, ci, co, 3, d, d, mode, 0.01, 512, st) == 0
+        yw = torch.full((n, 16 + co + 8, h, w), 7.0, dtype=torch.float16, device="cuda").contiguous(memory_format=torch.channels_last)
+        y = yw[:, 16:16 + co]
+        assert L.pp_conv_own_ld_f16(vp(x.data_ptr()), vp(wt.data_ptr()), vp(b.data_ptr()), vp(ex.data_ptr()) if mode else None,
+                                    vp(y.data_ptr()), n, h, w, ci, co, 3, d, d, mode, 0.01, 512, x.stride(1) and xw.shape[1],
+                                    yw.shape[1], st) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(y, want)
+        assert (yw[:, :16] == 7.0).all() and (yw[:, 16 + co:] == 7.0).all()
+    assert L.pp_conv_own_ld_f16(vp(x.data_ptr()), vp(wt.data_ptr()), vp(b.data_ptr()), None, vp(y.data_ptr()), n, h, w, ci, co, 3, d, d,
+                                0, 0.01, 128, xw.shape[1], yw.shape[1], st) == -6     # the implicit-GEMM kernels read packed pixels
+
+
+@pytest.mark.parametrize("shape", [
     # n, c_in, c_out, h_low, w_low: the convolution runs at (2 h_low, 2 w_low)
     (2, 64, 128, 16, 16),       # 32-wide tiles
     (1, 128, 256, 8, 64),       # 128-wide tiles, two output-channel tiles
