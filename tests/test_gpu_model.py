@@ -987,3 +987,41 @@ def test_demo_image_script_draws_the_injected_people(tmp_path, flags):
     assert out.shape == img.shape and out.dtype == np.uint8
     changed = (out != img).any(axis=2)
     assert 500 < changed.sum() < 0.5 * changed.size          # skeletons drawn, most of the image untouched
+    # ... and drawn WHERE the people are: every joint of the injected scene (a local maximum of its keypoint channel, at a quarter
+    # of the image resolution) has drawn pixels next to it -- in the reference's joint / pair colours on the refactored branches
+    # (utils/common.py:240-264: discs and lines in CocoColors), blended limb ellipses on the original one (demo_image.py:174-240)
+    from scipy import ndimage
+    from posepaf import synth
+    from utils import draw
+    scene = synth.make_net_output(3, 4242, h=64, w=64, noise=0.0, dtype=np.float32, flip=False)[0]
+    palette = {tuple(c) for c in draw.CocoColors}
+    joints = hits = 0
+    for part in range(18):
+        ch = scene[30 + part]
+        for y, x in zip(*np.nonzero((ch == ndimage.maximum_filter(ch, 5)) & (ch > 0.5))):
+            win = (slice(max(0, 4 * y - 4), 4 * y + 9), slice(max(0, 4 * x - 4), 4 * x + 9))
+            joints += 1
+            if flags:
+                hits += any(tuple(px) in palette for px in out[win][changed[win]])
+            else:
+                hits += bool(changed[win].any())
+    assert joints >= 3 * 10 and hits >= 0.9 * joints, (joints, hits)
+
+
+def test_inference_speed_script_prints_the_reference_log_lines():
+    """improved-body-parts_amd/test_inference_speed.py (reference test_inference_speed.py:91-120): the forward-only loop with one
+    synchronize per batch and the reference's `Test: [i/n] Time .. Speed ..` line; fused model under graph replay and the plain
+    nn.Module eagerly."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import PKG
+    for extra in (["--batch", "4", "--size", "256", "256"], ["--batch", "2", "--size", "128", "192", "--plain", "--no_graph"]):
+        r = subprocess.run([sys.executable, os.path.join(PKG, "test_inference_speed.py"), "--iters", "4", "--json", "--opt-level", "O1",
+                            *extra], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = r.stdout.strip().splitlines()
+        assert sum(ln.startswith("==================>Test: [") and "Speed" in ln for ln in lines) == 4
+        out = json.loads(lines[-1])
+        assert out["value"] > 0 and out["batch"] == int(extra[1])
