@@ -494,6 +494,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     constexpr int NW = 6;                // weight ring
     constexpr int AHEAD = NW - 1;        // the slice of phase ph + AHEAD is issued while phase ph is multiplied, into the slot phase ph - 1 read
     constexpr int HP = 56;               // halo pieces per buffer: 7 per wave (pieces past the halo are zero-page reads)
+    constexpr int NPW = (LGTW == 7 || D > 1) ? 7 : 6;   // pieces a wave really loads: the narrower tiles' halos (<= 45 pieces) need six
     static_assert(BN == 128, "one weight sub-tile per wave and phase");
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int halo_bytes = HP * SUB;
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
         int ln = lane;
         asm volatile("" : "+v"(ln));   // recomputed per tile: hoisted, the per-piece halo coordinates would sit in 20 registers
 #pragma unroll
-        for (int t = 0; t < 7; t++) {
+        for (int t = 0; t < NPW; t++) {
             const int piece = t * 8 + wave;
             const int phys = piece * SUB + ln * 16;
             const int logical = phys ^ (((phys >> 8) & 1) << 5);
@@ -643,7 +644,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     auto stage_first = [&]() {
         st_cb = 0, st_tap = 0, st_slot = 0;
 #pragma unroll
-        for (int t = 0; t < 7; t++) stage_halo(t, 0, 0);
+        for (int t = 0; t < NPW; t++) stage_halo(t, 0, 0);
         for (int q = 0; q < AHEAD && q < np; q++) stage_w();
     };
     unsigned long long acc_t[6] = {0, 0, 0, 0, 0, 0}, t_prev = 0;   // DIAGNOSTIC (MASK bit 1024): cycles per section, summed over tiles
@@ -701,7 +702,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     // LDS returns data in order, so lgkmcnt is counted like vmcnt: before pixel tile i of half A the reads issued after ITS
     // fragment are tiles i+1..7 of the previous phase and this phase's two weight reads: lgkmcnt(9 - i).
     // DMA schedule of a wave, per tap: one weight sub-tile (slice ph + AHEAD, into the ring slot phase ph - 1 read from), plus,
-    // while a next channel block exists, its halo pieces: 2, 2, 1, 1, 1 at taps 0..4 -- every piece is KEEP phases old when tap
+    // while a next channel block exists, its halo pieces: 2, 2, 1, 1 (, 1) at taps 0..3 (4) -- every piece is KEEP phases old when tap
     // 7 ends.  After the MFMAs the wave waits until only the DMA of the last KEEP phases is in flight (counted vmcnt; the
     // count is the schedule's, a compile-time sum), then the barrier publishes what landed: the weight slice of phase ph + 2,
     // whose fragments 0, 1 are read in half B of the next phase.  No dummy DMA anywhere.
@@ -715,8 +716,8 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
         constexpr bool halo = decltype(HALO)::value;     // a next channel block exists: its halo streams in
         constexpr int ntap = tap == NT - 1 ? 0 : tap + 1;
         // halo pieces issued per tap.  A piece is waited for KEEP = 3 taps after its issue and must have landed when the block ends:
-        // nine taps spread them 2-2-1-1-1 over taps 0..4, four taps issue all seven at tap 0.
-        constexpr auto halo_at = [](int t) { return t < 0 ? 0 : (NT == 9 ? (t <= 1 ? 2 : (t <= 4 ? 1 : 0)) : (t == 0 ? 7 : 0)); };
+        // nine taps spread them 2-2-1-1(-1) over taps 0..3 (4), four taps issue all NPW at tap 0.
+        constexpr auto halo_at = [](int t) { return t < 0 ? 0 : (NT == 9 ? (t <= 1 ? 2 : (t <= NPW - 3 ? 1 : 0)) : (t == 0 ? NPW : 0)); };
         constexpr int in_flight = KEEP + (halo ? halo_at(tap) + halo_at(tap - 1) + halo_at(tap - 2) : 0);
         static_assert(KEEP == 3, "in_flight sums the halo pieces of three taps");
         // The two waves of a SIMD (w and w + 4) issue their DMA at different times: a piece blocks its wave for 60-100 cycles, and
@@ -732,12 +733,12 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
                             stage_halo(3, cb + 1, (cb + 1) & 1);
                             stage_halo(4, cb + 1, (cb + 1) & 1);
                             stage_halo(5, cb + 1, (cb + 1) & 1);
-                            stage_halo(6, cb + 1, (cb + 1) & 1);
+                            if (NPW == 7) stage_halo(6, cb + 1, (cb + 1) & 1);
                         }
                     } else if (tap <= 1) {
                         stage_halo(2 * tap, cb + 1, (cb + 1) & 1);
                         stage_halo(2 * tap + 1, cb + 1, (cb + 1) & 1);
-                    } else if (tap <= 4) {
+                    } else if (tap <= NPW - 3) {
                         stage_halo(tap + 2, cb + 1, (cb + 1) & 1);
                     }
                 }
@@ -926,7 +927,7 @@ bool halo_geometry(const ConvParams &p, HaloParams &g) {
         g.nhalo = g.gimg * (p.H + 2) * (tw + 2);
     }
     g.npieces = (g.nhalo + 15) / 16;
-    return g.npieces <= 56;   // at most 7 pieces per wave and channel block
+    return g.npieces <= (g.lgTW == 7 || p.dil > 1 ? 56 : 48);   // 7 pieces per wave and channel block (six for the narrower tiles: NPW)
 }
 
 
