@@ -428,7 +428,9 @@ class GpuEngine:
           (1) the post-processing of the batch's network output once more with the person assembly as its OWN launch
               (pp_debug_set_mode 1, eager) -- every record byte must equal what the graph replay produced;
           (2) the fused fp16 forward (kernels picked by the tuner, as replayed) against the plain nn.Module on PyTorch-ROCm
-              (MIOpen convolutions, BatchNorm unfolded) for the first two images of the batch.
+              (MIOpen convolutions, BatchNorm unfolded) for the first two images of the batch;
+          (3) the fused forward of the whole batch twice: bit-identical outputs (a race detector: the hand-counted LDS-DMA of the
+              convolution kernels goes wrong only under load, and then differently every time).
         -> dict for the JSON line; ["ok"] False invalidates the run."""
         torch = self.torch
         import numpy as np
@@ -453,7 +455,14 @@ class GpuEngine:
             nchk = min(2, p.b)
             with torch.no_grad():
                 x = preprocess_batch(p.images, True, torch.float16)
-                fused = self.model(x)[: 2 * nchk].float()
+                whole = self.model(x).clone()
+                again = self.model(x)
+                # (the kernels have no atomics on the data path: two passes over the same batch must agree to the bit -- a
+                # difference means a kernel read operands that were still in flight)
+                out["forward_twice_bit_identical"] = bool(torch.equal(whole, again))
+                out["ok"] &= out["forward_twice_bit_identical"]
+                fused = whole[: 2 * nchk].float()
+                del whole, again
                 bench_flag = torch.backends.cudnn.benchmark
                 torch.backends.cudnn.benchmark = False
                 plain = build_inference_model(self.dev, fused=False)

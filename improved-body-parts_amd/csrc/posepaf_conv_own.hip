@@ -494,7 +494,11 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     constexpr int NW = 6;                // weight ring
     constexpr int AHEAD = NW - 1;        // the slice of phase ph + AHEAD is issued while phase ph is multiplied, into the slot phase ph - 1 read
     constexpr int HP = 56;               // halo pieces per buffer: 7 per wave (pieces past the halo are zero-page reads)
+#ifdef PP_HALO_NPW7   // A/B build (tools): seven pieces on every tile width
+    constexpr int NPW = 7;
+#else
     constexpr int NPW = (LGTW == 7 || D > 1) ? 7 : 6;   // pieces a wave really loads: the narrower tiles' halos (<= 45 pieces) need six
+#endif
     static_assert(BN == 128, "one weight sub-tile per wave and phase");
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int halo_bytes = HP * SUB;
@@ -718,7 +722,12 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
         // halo pieces issued per tap.  A piece is waited for KEEP = 3 taps after its issue and must have landed when the block ends:
         // nine taps spread them 2-2-1-1(-1) over taps 0..3 (4), four taps issue all NPW at tap 0.
         constexpr auto halo_at = [](int t) { return t < 0 ? 0 : (NT == 9 ? (t <= 1 ? 2 : (t <= NPW - 3 ? 1 : 0)) : (t == 0 ? NPW : 0)); };
-        constexpr int in_flight = KEEP + (halo ? halo_at(tap) + halo_at(tap - 1) + halo_at(tap - 2) : 0);
+        // The NEW halo buffer is first read by the fragment refill in half B of the block's LAST tap (after flip_R), so its pieces
+        // must have landed when the tap before that ends.  Nine taps: the last piece is issued at tap 4 and is KEEP phases old
+        // when tap 7 ends.  Four taps: every piece is issued at tap 0 and must be down when tap 2 ends -- only the three weight
+        // slices issued after them may still be in flight there (counting the pieces of "the last three taps" at tap 2 let the
+        // refill read a halo that was still arriving: wrong pixels under load, found by tools/collapsed_repeat.py).
+        constexpr int in_flight = KEEP + (!halo ? 0 : NT == 9 ? halo_at(tap) + halo_at(tap - 1) + halo_at(tap - 2) : (tap <= 1 ? NPW : 0));
         static_assert(KEEP == 3, "in_flight sums the halo pieces of three taps");
         // The two waves of a SIMD (w and w + 4) issue their DMA at different times: a piece blocks its wave for 60-100 cycles, and
         // with both waves there at once right after the barrier the matrix pipe idles; group 1 issues between the halves.

@@ -330,6 +330,60 @@ extern "C" int pp_channel_mean_finish_f16(const void *partial_ws, void *out, int
     return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
 }
 
+// ------------------------------------------------------------------------------------------------ NHWC -> planes
+// The last head writes its prediction pixel-major (n, h, w, 64: 50 channels + zero padding, see pp_pw_f16); K_A / K_B read
+// channel planes (n, 50, h, w) -- the layout of the reference's network output (models/posenet.py:193-202).  A strided
+// `.contiguous()` copy does this transposition at about 1 TB/s; here a workgroup moves a tile of 64 pixels x 64 channels through
+// LDS: 16-byte reads along the channels, 16-byte writes along the pixels (odd LDS row pitch in dwords: no bank conflicts on the
+// transposing side).
+namespace {
+__global__ __launch_bounds__(256) void k_nhwc64_to_planes(const __half *__restrict__ x, __half *__restrict__ y, long hw, int c_out) {
+    __shared__ __half tile[64][66];                    // [channel][pixel], pitch 33 dwords
+    const long p0 = (long)blockIdx.x * 64;             // first pixel of the tile inside image blockIdx.y
+    const __half *src = x + ((long)blockIdx.y * hw + p0) * 64;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int q = threadIdx.x + r * 256;           // 16-byte chunk: pixel q / 8, channels 8 (q % 8) ..
+        const int px = q >> 3, c8 = (q & 7) * 8;
+        if (p0 + px < hw) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(src + (long)px * 64 + c8);
+            const __half *h = reinterpret_cast<const __half *>(&v);
+#pragma unroll
+            for (int e = 0; e < 8; e++) tile[c8 + e][px] = h[e];
+        }
+    }
+    __syncthreads();
+    __half *dst = y + (long)blockIdx.y * c_out * hw + p0;
+    const bool whole = p0 + 64 <= hw && (hw & 7) == 0;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int q = threadIdx.x + r * 256;           // 16-byte chunk: channel q / 8, pixels 8 (q % 8) ..
+        const int c = q >> 3, p8 = (q & 7) * 8;
+        if (c >= c_out) continue;
+        if (whole) {
+            uint4 v;
+            __half *h = reinterpret_cast<__half *>(&v);
+#pragma unroll
+            for (int e = 0; e < 8; e++) h[e] = tile[c][p8 + e];
+            *reinterpret_cast<uint4 *>(dst + (long)c * hw + p8) = v;
+        } else {
+            for (int e = 0; e < 8; e++)
+                if (p0 + p8 + e < hw) dst[(long)c * hw + p8 + e] = tile[c][p8 + e];
+        }
+    }
+}
+}  // namespace
+
+// x: DEVICE (n, hw, 64) fp16 (an NHWC tensor of 64 channels); y: DEVICE (n, c_out, hw) fp16, c_out <= 64: y[i][c][p] = x[i][p][c].
+extern "C" int pp_nhwc64_to_planes_f16(const void *x, void *y, int n, long hw, int c_out, void *stream) {
+    if (!x || !y || n <= 0 || hw <= 0 || c_out <= 0 || c_out > 64) return PP_ERR_BAD_ARG;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) return PP_ERR_BAD_ARG;
+    if (n > 65535) return PP_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_nhwc64_to_planes, dim3((unsigned)((hw + 63) / 64), (unsigned)n), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const __half *>(x), static_cast<__half *>(y), hw, c_out);
+    return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
+}
+
 // ------------------------------------------------------------------------------------------------ A0 pre-processing
 // utils/parse_skeletons.py:52-73 + utils/util.py:44-65 for a batch of equally sized BGR uint8 images (scale 1):
 // pad bottom/right to a multiple of `pad_to` with `pad_value`, x / 255 -> float, and emit each image followed by the

@@ -29,6 +29,7 @@ import torch
 
 from . import skeleton as sk
 from ._lib import RECORD_BYTES, PosePafError
+from .fused_model import to_planes
 
 
 def padded_shape(h: int, w: int, mult: int = sk.MAX_DOWNSAMPLE):
@@ -147,7 +148,7 @@ class InferenceEngine:
                 sk.PAD_VALUE, 1, C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)))
             out = self.model(x)
             out = out[-1][0] if isinstance(out, (list, tuple)) else out
-            maps = out.contiguous().view(b, 2, sk.NUM_CH, hp // 4, wp // 4)
+            maps = to_planes(out).view(b, 2, sk.NUM_CH, hp // 4, wp // 4)
             if p.bank is not None:
                 maps = torch.addcmul(p.bank.index_select(0, p.bank_idx), maps, self.inject_scale)
         p.maps = maps

@@ -164,6 +164,19 @@ def _cl(t):
     return t if t.is_contiguous(memory_format=torch.channels_last) else t.contiguous(memory_format=torch.channels_last)
 
 
+def to_planes(t: torch.Tensor) -> torch.Tensor:
+    """The contiguous (n, c, h, w) copy of a prediction: the [:, :c] view of the last head's 64-channel pixel-major output goes
+    through pp_nhwc64_to_planes_f16 (one streaming pass); anything else through torch's strided copy."""
+    n, c, h, w = t.shape
+    if (t.is_cuda and t.dtype == torch.float16 and c <= 64 and t.stride() == (h * w * 64, 1, w * 64, 64)
+            and t.data_ptr() % 16 == 0 and n <= 65535):
+        from . import _lib
+        y = torch.empty((n, c, h, w), dtype=t.dtype, device=t.device)
+        _lib.check(_lib.load().pp_nhwc64_to_planes_f16(_ptr(t), _ptr(y), n, h * w, c, _stream(t)))
+        return y
+    return t.contiguous()
+
+
 def _slice_ld(t):
     """pixel stride (elements) of t when it is channels-last OR a channel slice of a channels-last tensor, else None"""
     n, c, h, w = t.shape

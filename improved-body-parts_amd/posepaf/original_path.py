@@ -19,6 +19,7 @@ from . import skeleton as sk
 from ._lib import RECORD_BYTES
 from .api import PosePostProcessor, records_to_numpy
 from .pipeline import preprocess_batch
+from .fused_model import to_planes
 
 
 def _p(t):
@@ -150,7 +151,7 @@ class OriginalPathProcessor:
             x = preprocess_batch(scaled, True, dtype)                       # pad to /64, /255, mirror
             ph, pw = x.shape[1:3]
             out = model(x)
-            maps = (out[-1][0] if isinstance(out, (list, tuple)) else out).contiguous()
+            maps = to_planes(out[-1][0] if isinstance(out, (list, tuple)) else out)
             maps = maps.view(B, 2, sk.NUM_CH, maps.shape[-2], maps.shape[-1])
             self.accumulate(maps, ph - sh, pw - sw, len(multiplier))
         return records_to_numpy(self.finish(B, thre1))

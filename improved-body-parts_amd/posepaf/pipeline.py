@@ -15,6 +15,7 @@ import torch
 
 from . import skeleton as sk
 from .api import PosePostProcessor, records_to_numpy
+from .fused_model import to_planes
 
 
 def preprocess_batch(images_u8: torch.Tensor, flip: bool = True, dtype=torch.float32) -> torch.Tensor:
@@ -60,7 +61,7 @@ class PosePipeline:
         out = self.model(x)
         maps = out[-1][0] if isinstance(out, (list, tuple)) else out
         ns = 2 if self.flip else 1
-        return maps.contiguous().view(-1, ns, sk.NUM_CH, maps.shape[-2], maps.shape[-1])
+        return to_planes(maps).view(-1, ns, sk.NUM_CH, maps.shape[-2], maps.shape[-1])
 
     @torch.no_grad()
     def run_async(self, images_u8: torch.Tensor, min_img_size: int | None = None, inject: torch.Tensor | None = None):

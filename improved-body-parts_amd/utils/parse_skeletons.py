@@ -29,6 +29,7 @@ import torch
 from posepaf import _lib
 from posepaf import skeleton as sk
 from posepaf.pipeline import preprocess_batch
+from posepaf.fused_model import to_planes
 
 NUM_KEYPOINTS = 18
 NUM_HEATMAPS = NUM_KEYPOINTS + 2
@@ -56,7 +57,7 @@ def predict_refactor(image, model, test_cfg, model_cfg, input_image_path, flip_a
     with torch.no_grad():
         x = preprocess_batch(img, True, dtype if dtype in (torch.float16, torch.float32) else torch.float32)
         out = model(x)
-        maps = (out[-1][0] if isinstance(out, (list, tuple)) else out).contiguous()   # (2, 50, h, w)
+        maps = to_planes(out[-1][0] if isinstance(out, (list, tuple)) else out)   # (2, 50, h, w)
     h, w = maps.shape[-2:]
     heat = torch.empty((h, w, NUM_HEATMAPS), dtype=torch.float32, device=dev)
     paf = torch.empty((h, w, NUM_PAFS), dtype=torch.float32, device=dev)
@@ -140,7 +141,7 @@ def predict(image, model, test_cfg, model_cfg, input_image_path, flip_avg=True, 
             sh, sw = scaled.shape[1:3]
             x = preprocess_batch(scaled, True, dtype)                      # pad to /64 with 128, /255, mirror (:206-226)
             out = model(x)
-            maps = (out[-1][0] if isinstance(out, (list, tuple)) else out).contiguous()
+            maps = to_planes(out[-1][0] if isinstance(out, (list, tuple)) else out)
             if maps.dtype not in (torch.float16, torch.float32):
                 maps = maps.float()
             maps = maps.view(1, 2, sk.NUM_CH, maps.shape[-2], maps.shape[-1])

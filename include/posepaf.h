@@ -164,6 +164,10 @@ PP_API int pp_conv_own_sums_splits(int h, int w);
 PP_API int pp_conv_own_sums_f16(const void *x, const void *w, const void *bias, void *y, void *sums_ws, int n, int h, int wd, int c_in,
                                 int c_out, float slope, void *stream);
 PP_API int pp_channel_mean_finish_f16(const void *partial_ws, void *out, int n, long hw, int channels, int splits, void *stream);
+/* The layout change between the forward and the post-processing: x DEVICE (n, hw, 64) fp16 -- the last head's pixel-major output,
+ * 50 channels + zero padding -- to channel planes y DEVICE (n, c_out, hw), c_out <= 64: the (N, 50, h, w) tensor the reference's
+ * network returns (models/posenet.py:193-202) and pp_process_batch reads.  One pass at streaming speed instead of a strided copy. */
+PP_API int pp_nhwc64_to_planes_f16(const void *x, void *y, int n, long hw, int c_out, void *stream);
 /* SE excitation: y[n][p][c] = x[n][p][c] * scale[n][c] on NHWC fp16 (x: (n, hw, channels), scale: fp16 (n, channels)); y may be x. */
 PP_API int pp_channel_scale_f16(const void *x, const void *scale, void *y, int n, long hw, int channels, void *stream);
 
