@@ -330,6 +330,68 @@ extern "C" int pp_channel_mean_finish_f16(const void *partial_ws, void *out, int
     return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
 }
 
+// ------------------------------------------------------------------------------------------------ SE excitation, one launch
+// models/layers_transposed.py:289-310 after the squeeze: s = sigmoid(W2 leaky(W1 mean + b1) + b2) per sample.  The torch path is
+// five launches per SE block (finish of the channel sums, two GEMMs of a few hundred kFLOP, LeakyReLU, sigmoid) -- 16 blocks per
+// forward; here one workgroup per sample does all of it.  The roundings are those of the fp16 torch modules it replaces: the
+// mean, the hidden vector (after the bias, again after LeakyReLU) and the gains are rounded to binary16, sums are fp32.
+namespace {
+__global__ __launch_bounds__(256) void k_se_gains(const float *__restrict__ partial, const __half *__restrict__ mean_in,
+                                                  const __half *__restrict__ w1, const __half *__restrict__ b1,
+                                                  const __half *__restrict__ w2, const __half *__restrict__ b2, __half *__restrict__ out,
+                                                  int c, int hidden, int splits, float inv_hw, float slope) {
+    extern __shared__ float se_lds[];      // [c] mean, [hidden] hidden
+    float *s_mean = se_lds, *s_hid = se_lds + c;
+    const int n = blockIdx.x;
+    for (int ch = threadIdx.x; ch < c; ch += 256) {
+        float m;
+        if (partial) {
+            float t = 0.f;
+            for (int sp = 0; sp < splits; sp++) t += partial[((size_t)n * splits + sp) * c + ch];
+            m = __half2float(__float2half_rn(t * inv_hw));
+        } else {
+            m = __half2float(mean_in[(size_t)n * c + ch]);
+        }
+        s_mean[ch] = m;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int j = wave; j < hidden; j += 4) {   // one wave per hidden unit: dot over the channels
+        float t = 0.f;
+        for (int ch = lane; ch < c; ch += 64) t += __half2float(w1[(size_t)j * c + ch]) * s_mean[ch];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d);
+        if (lane == 0) {
+            float h = __half2float(__float2half_rn(t + __half2float(b1[j])));      // nn.Linear's fp16 output
+            h = h > 0.f ? h : h * slope;
+            s_hid[j] = __half2float(__float2half_rn(h));                          // LeakyReLU's fp16 output
+        }
+    }
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < c; ch += 256) {
+        float t = 0.f;
+        for (int j = 0; j < hidden; j++) t += __half2float(w2[(size_t)ch * hidden + j]) * s_hid[j];
+        const float z = __half2float(__float2half_rn(t + __half2float(b2[ch])));
+        out[(size_t)n * c + ch] = __float2half_rn(1.0f / (1.0f + expf(-z)));
+    }
+}
+}  // namespace
+
+// gains (n, c) fp16 = sigmoid(W2 leaky(W1 mean + b1) + b2).  Either partial_ws (n, splits, c) fp32 channel SUMS over hw pixels (as
+// pp_conv_own_sums_f16 / pp_channel_mean_f16's first pass leave them) or mean (n, c) fp16 is given, the other NULL.
+// w1: (hidden, c), b1: (hidden), w2: (c, hidden), b2: (c), all fp16 DEVICE.
+extern "C" int pp_se_gains_f16(const void *partial_ws, const void *mean, const void *w1, const void *b1, const void *w2, const void *b2,
+                               void *out, int n, long hw, int c, int hidden, int splits, float slope, void *stream) {
+    if ((!partial_ws) == (!mean) || !w1 || !b1 || !w2 || !b2 || !out || n <= 0 || c <= 0 || hidden <= 0 || (partial_ws && (hw <= 0 || splits <= 0)))
+        return PP_ERR_BAD_ARG;
+    if (c > 4096 || hidden > 1024) return PP_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_se_gains, dim3((unsigned)n), dim3(256), (size_t)(c + hidden) * sizeof(float), static_cast<hipStream_t>(stream),
+                       static_cast<const float *>(partial_ws), static_cast<const __half *>(mean), static_cast<const __half *>(w1),
+                       static_cast<const __half *>(b1), static_cast<const __half *>(w2), static_cast<const __half *>(b2),
+                       static_cast<__half *>(out), c, hidden, splits, partial_ws ? 1.0f / (float)hw : 0.f, slope);
+    return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
+}
+
 // ------------------------------------------------------------------------------------------------ NHWC -> planes
 // The last head writes its prediction pixel-major (n, h, w, 64: 50 channels + zero padding, see pp_pw_f16); K_A / K_B read
 // channel planes (n, 50, h, w) -- the layout of the reference's network output (models/posenet.py:193-202).  A strided

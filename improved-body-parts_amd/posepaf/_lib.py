@@ -28,7 +28,7 @@ RECORD_BYTES = RECORD_DTYPE.itemsize
 
 EXPORTS = [
     "pp_create", "pp_destroy", "pp_last_hip_error", "pp_status_string", "pp_device_available", "pp_process_batch", "pp_process_batch_py",
-    "pp_nms_batch", "pp_nms_batch_ex", "pp_time_kernels", "pp_bias_act_f16", "pp_maxpool2_f16", "pp_upsample2_f16", "pp_add3_f16", "pp_channel_mean_f16", "pp_channel_mean_finish_f16", "pp_nhwc64_to_planes_f16", "pp_conv_own_sums_splits", "pp_conv_own_sums_f16", "pp_channel_scale_f16", "pp_preprocess_u8", "pp_preprocess_u8_ragged", "pp_flip_average", "pp_pwconv_supported", "pp_pwconv_f16", "pp_conv_num_configs", "pp_conv_f16", "pp_conv_ld_f16", "pp_conv_own_supported", "pp_conv_own_f16", "pp_conv_own_ld_f16", "pp_conv_own_ex_f16", "pp_stem7x7_f16", "pp_conv_up2_collapsed_f16", "pp_pw_supported", "pp_pw_f16", "pp_pw_pool_f16", "pp_pw_cat_f16", "pp_conv_debug_clock", "pp_debug_set_stamps", "pp_debug_set_mode", "pp_read_peaks", "pp_read_connections", "pp_read_part_counts", "pp_read_connection_counts", "pp_debug_read_flags", "pp_read_records", "pp_process_paf_host",
+    "pp_nms_batch", "pp_nms_batch_ex", "pp_time_kernels", "pp_bias_act_f16", "pp_maxpool2_f16", "pp_upsample2_f16", "pp_add3_f16", "pp_channel_mean_f16", "pp_channel_mean_finish_f16", "pp_nhwc64_to_planes_f16", "pp_se_gains_f16", "pp_conv_own_sums_splits", "pp_conv_own_sums_f16", "pp_channel_scale_f16", "pp_preprocess_u8", "pp_preprocess_u8_ragged", "pp_flip_average", "pp_pwconv_supported", "pp_pwconv_f16", "pp_conv_num_configs", "pp_conv_f16", "pp_conv_ld_f16", "pp_conv_own_supported", "pp_conv_own_f16", "pp_conv_own_ld_f16", "pp_conv_own_ex_f16", "pp_stem7x7_f16", "pp_conv_up2_collapsed_f16", "pp_pw_supported", "pp_pw_f16", "pp_pw_pool_f16", "pp_pw_cat_f16", "pp_conv_debug_clock", "pp_debug_set_stamps", "pp_debug_set_mode", "pp_read_peaks", "pp_read_connections", "pp_read_part_counts", "pp_read_connection_counts", "pp_debug_read_flags", "pp_read_records", "pp_process_paf_host",
     "pp_get_num_humans", "pp_get_part_peak_id", "pp_get_score", "pp_get_part_x", "pp_get_part_y",
     "pp_get_part_score", "pp_get_status", "pp_py_find_connections_host", "pp_py_find_humans_host", "pp_original_accumulate", "pp_original_accumulate_all", "pp_original_finish",
     "pp_resize_u8_cubic",
@@ -97,6 +97,7 @@ def load():
     L.pp_conv_f16.argtypes = [vp, vp, vp, vp, vp] + [C.c_int] * 9 + [C.c_float, C.c_int, vp]
     L.pp_conv_ld_f16.argtypes = [vp, vp, vp, vp, vp] + [C.c_int] * 9 + [C.c_float, C.c_int, C.c_int, C.c_int, vp]
     L.pp_conv_own_f16.argtypes = [vp, vp, vp, vp, vp] + [C.c_int] * 9 + [C.c_float, C.c_int, vp]
+    L.pp_se_gains_f16.argtypes = [vp] * 7 + [C.c_int, C.c_long, C.c_int, C.c_int, C.c_int, C.c_float, vp]
     L.pp_nhwc64_to_planes_f16.argtypes = [vp, vp, C.c_int, C.c_long, C.c_int, vp]
     L.pp_conv_own_ld_f16.argtypes = [vp, vp, vp, vp, vp] + [C.c_int] * 9 + [C.c_float, C.c_int, C.c_int, C.c_int, vp]
     L.pp_conv_own_ex_f16.argtypes = [vp, vp, vp, vp, vp, vp, vp] + [C.c_int] * 9 + [C.c_float, C.c_int, C.c_int, vp]

@@ -44,6 +44,7 @@ USE_SLICE_OUTPUT = True     # the backbone's concatenation is written in place b
 USE_COLLAPSED_UP2 = True    # conv3x3(upsample2(x)) as four 2x2 convolutions of x (2.25x fewer multiply-adds)
 USE_FOLDED_MERGE = True     # merge_preds(head(f)) is linear in f: folded into merge_features' weights at load time
 USE_CAT_SKIP = True         # a residual block's last 1x1 and its 1x1 skip convolution as one product over [t ; x]
+USE_SE_KERNEL = True        # the SE block's excitation (two tiny linear layers, LeakyReLU, sigmoid) in one launch per block
 USE_POOL_FUSION = True      # the hourglass' 2x2 max-pools leave the 1x1 kernel that produces their input as a second output
 _conv_choice: dict = {}   # shape key -> tile configuration id, or -1 = MIOpen convolution + k_bias_act pass
 _conv_timing: dict = {}   # shape key -> {"miopen": ms, cfg: ms, ...} measured by the autotune (diagnostics)
@@ -645,10 +646,12 @@ class FConv(nn.Module):
                                    h * w, c, k, k, 1 if res is not None else 0, LEAK if self.act else 1.0, _stream(x))
         return y if rc == 0 else None
 
-    def forward_mean(self, x):
+    def forward_mean(self, x, partial: bool = False):
         """-> (y, channel mean of y (n, c_out)) with y = act(conv(x) + bias): the SE squeeze of models/layers_transposed.py:298-303.
         On the 3x3 halo-tile kernel the per-tile channel sums leave the convolution's epilogue (pp_conv_own_sums_f16) and only a
-        tiny reduction follows; timed once per shape against convolution + the two-pass channel mean."""
+        tiny reduction follows; timed once per shape against convolution + the two-pass channel mean.
+        partial=True: the fused form hands over the partial sums themselves, (ws (n, splits, c_out) fp32, splits, h * w), for a
+        consumer that finishes them on the way (FSE / pp_se_gains_f16)."""
         from . import _lib
         n, c, h, w = x.shape
         k = self.weight.shape[0]
@@ -663,17 +666,19 @@ class FConv(nn.Module):
             y = self(x)
             return y, channel_mean(y)
 
-        def fused():
+        def fused(hand_over=False):
             xx = _cl(x)
             if not self.weight.is_contiguous(memory_format=torch.channels_last):
                 self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
             y = torch.empty((n, k, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
             ws = torch.empty((n, splits, k), dtype=torch.float32, device=x.device)
-            mean = torch.empty((n, k), dtype=x.dtype, device=x.device)
             rc = L.pp_conv_own_sums_f16(_ptr(xx), _ptr(self.weight), _ptr(self.bias), _ptr(y), _ptr(ws), n, h, w, c, k,
                                         LEAK if self.act else 1.0, _stream(x))
             if rc != 0:
                 return None
+            if hand_over:
+                return y, (ws, splits, h * w)
+            mean = torch.empty((n, k), dtype=x.dtype, device=x.device)
             _lib.check(L.pp_channel_mean_finish_f16(_ptr(ws), _ptr(mean), n, h * w, k, splits, _stream(x)))
             return y, mean
 
@@ -691,7 +696,7 @@ class FConv(nn.Module):
             _conv_choice[key] = choice
             _note(key, choice)
         if choice:
-            out = fused()
+            out = fused(partial)
             if out is not None:
                 return out
         return separate()
@@ -973,10 +978,34 @@ class FSE(nn.Module):
         super().__init__()
         self.fc1, self.fc2 = se.fc[0], se.fc[2]
 
-    def forward(self, x, fold: bool = False, mean=None):
-        """mean: the channel mean of x when its producer already made it (FConv.forward_mean)"""
+    def gains(self, x, mean=None):
+        """sigmoid(fc2(leaky(fc1(mean)))) (n, c): one launch of pp_se_gains_f16 on the GPU (USE_SE_KERNEL), the torch modules elsewhere.
+        mean: None, the (n, c) mean, or the producer's partial channel sums (ws, splits, hw) -- see FConv.forward_mean."""
+        n, c = x.shape[:2]
+        if (USE_SE_KERNEL and x.is_cuda and x.dtype == torch.float16 and self.fc1.weight.dtype == torch.float16
+                and self.fc1.bias is not None and self.fc2.bias is not None):
+            from . import _lib
+            out = torch.empty((n, c), dtype=x.dtype, device=x.device)
+            hid = self.fc1.weight.shape[0]
+            if isinstance(mean, tuple):
+                ws, splits, hw = mean
+                rc = _lib.load().pp_se_gains_f16(_ptr(ws), None, _ptr(self.fc1.weight), _ptr(self.fc1.bias), _ptr(self.fc2.weight),
+                                                 _ptr(self.fc2.bias), _ptr(out), n, hw, c, hid, splits, 0.01, _stream(x))
+            else:
+                m = (channel_mean(x) if mean is None else mean).contiguous()
+                rc = _lib.load().pp_se_gains_f16(None, _ptr(m), _ptr(self.fc1.weight), _ptr(self.fc1.bias), _ptr(self.fc2.weight),
+                                                 _ptr(self.fc2.bias), _ptr(out), n, 0, c, hid, 0, 0.01, _stream(x))
+            _lib.check(rc)
+            return out
+        if isinstance(mean, tuple):
+            ws, splits, hw = mean
+            mean = (ws.sum(dim=1) / hw).to(x.dtype)
         y = channel_mean(x) if mean is None else mean
-        y = torch.sigmoid(self.fc2(F.leaky_relu(self.fc1(y), 0.01)))
+        return torch.sigmoid(self.fc2(F.leaky_relu(self.fc1(y), 0.01)))
+
+    def forward(self, x, fold: bool = False, mean=None):
+        """mean: the channel mean of x (or the partial sums behind it) when its producer already made it (FConv.forward_mean)"""
+        y = self.gains(x, mean)
         if fold and x.is_cuda and x.dtype == torch.float16 and USE_PW and USE_OWN_CONV:
             return Scaled(x, y)            # the consumers (1x1 head / merge convolutions) multiply while they read
         return channel_scale(x, y)
@@ -988,7 +1017,7 @@ class FFeature(nn.Module):
         self.c1, self.c2, self.se = _fconv_from_block(seq[0]), _fconv_from_block(seq[1]), FSE(seq[2])
 
     def forward(self, x, fold: bool = False):
-        y, mean = self.c2.forward_mean(self.c1(x))
+        y, mean = self.c2.forward_mean(self.c1(x), partial=True)
         return self.se(y, fold, mean)
 
 

@@ -164,6 +164,12 @@ PP_API int pp_conv_own_sums_splits(int h, int w);
 PP_API int pp_conv_own_sums_f16(const void *x, const void *w, const void *bias, void *y, void *sums_ws, int n, int h, int wd, int c_in,
                                 int c_out, float slope, void *stream);
 PP_API int pp_channel_mean_finish_f16(const void *partial_ws, void *out, int n, long hw, int channels, int splits, void *stream);
+/* The SE block's excitation (models/layers_transposed.py:289-310) in one launch: gains (n, c) fp16 = sigmoid(W2 leaky(W1 mean + b1)
+ * + b2), one workgroup per sample, roundings as the fp16 torch modules it replaces.  Input: partial_ws (n, splits, c) fp32 channel
+ * sums over hw pixels (pp_conv_own_sums_f16 / the first pass of pp_channel_mean_f16) OR mean (n, c) fp16 -- the other NULL.
+ * w1 (hidden, c), b1 (hidden), w2 (c, hidden), b2 (c): fp16 DEVICE. */
+PP_API int pp_se_gains_f16(const void *partial_ws, const void *mean, const void *w1, const void *b1, const void *w2, const void *b2,
+                           void *out, int n, long hw, int c, int hidden, int splits, float slope, void *stream);
 /* The layout change between the forward and the post-processing: x DEVICE (n, hw, 64) fp16 -- the last head's pixel-major output,
  * 50 channels + zero padding -- to channel planes y DEVICE (n, c_out, hw), c_out <= 64: the (N, 50, h, w) tensor the reference's
  * network returns (models/posenet.py:193-202) and pp_process_batch reads.  One pass at streaming speed instead of a strided copy. */

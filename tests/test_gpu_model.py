@@ -1103,3 +1103,35 @@ def test_own_convolution_kernels_are_deterministic_under_load():
             repeat(lambda y: L.pp_pw_f16(vp(x.data_ptr()), None, vp(wt.data_ptr()), vp(b.data_ptr()), None, None, vp(y.data_ptr()), None,
                                          n * h * w, h * w, ci, co, co, 0, 0.01, st), (n, co, h, w), check)
         del x
+
+
+@pytest.mark.parametrize("shape", [(5, 256, 16, 40), (3, 768, 48, 7), (2, 384, 24, 1)])
+def test_se_excitation_kernel_matches_the_torch_modules(shape):
+    """pp_se_gains_f16 (models/layers_transposed.py:289-310: Linear -> LeakyReLU -> Linear -> Sigmoid on the channel means) from
+    partial channel sums and from a ready mean, against the fp16 torch modules on the same mean: the roundings sit at the same
+    places, the fp32 sums run in another order -- one binary16 ulp of a value below 1."""
+    import ctypes as C
+    from posepaf import _lib
+    L = _lib.load()
+    n, c, hid, splits = shape
+    g = torch.Generator(device="cpu").manual_seed(41)
+    fc1, fc2 = torch.nn.Linear(c, hid), torch.nn.Linear(hid, c)
+    with torch.no_grad():
+        fc1.weight.copy_(torch.randn(fc1.weight.shape, generator=g) / c ** 0.5), fc1.bias.copy_(torch.randn(hid, generator=g))
+        fc2.weight.copy_(torch.randn(fc2.weight.shape, generator=g)), fc2.bias.copy_(torch.randn(c, generator=g))
+    fc1, fc2 = fc1.cuda().half(), fc2.cuda().half()
+    hw = 4096
+    ws = (torch.randn(n, splits, c, generator=g) * 40 + 10).cuda()
+    mean = (ws.sum(dim=1) / hw).half()
+    with torch.no_grad():
+        want = torch.sigmoid(fc2(torch.nn.functional.leaky_relu(fc1(mean), 0.01))).float()
+    vp = C.c_void_p
+    st = vp(torch.cuda.current_stream().cuda_stream)
+    args = (vp(fc1.weight.data_ptr()), vp(fc1.bias.data_ptr()), vp(fc2.weight.data_ptr()), vp(fc2.bias.data_ptr()))
+    a = torch.full((n, c), float("nan"), dtype=torch.float16, device="cuda")
+    b = torch.full((n, c), float("nan"), dtype=torch.float16, device="cuda")
+    assert L.pp_se_gains_f16(vp(ws.data_ptr()), None, *args, vp(a.data_ptr()), n, hw, c, hid, splits, 0.01, st) == 0
+    assert L.pp_se_gains_f16(None, vp(mean.data_ptr()), *args, vp(b.data_ptr()), n, 0, c, hid, 0, 0.01, st) == 0
+    torch.cuda.synchronize()
+    assert (a.float() - want).abs().max().item() <= 1.5e-3 and (b.float() - want).abs().max().item() <= 1.5e-3
+    assert L.pp_se_gains_f16(vp(ws.data_ptr()), vp(mean.data_ptr()), *args, vp(a.data_ptr()), n, hw, c, hid, splits, 0.01, st) == -2
