@@ -531,6 +531,9 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     // swizzle (bit 9) would make 14 of 16 start offsets 2-way conflicted.
     // Wave w loads pieces w, w + 8, ..., w + 48 of every channel block (see the DMA schedule).
     int hsrc[7];   // byte offset inside the image for channel block 0, or -1: zero page (outside the image / past the halo)
+    // The 128-wide tiles' halos take 49 pieces (52 dilated): a seventh piece for wave 0 (waves 0..3) only.  The other waves skip
+    // the instruction -- a load of nothing still costs its issue slot on the CU's one load path -- and count one less (below).
+    const bool p6 = __builtin_amdgcn_readfirstlane(48 + wave < hp.npieces);
     unsigned woff = 0; // weight sub-tile of this wave: 16 output channels x 32 halves per phase (lane part of the offset)
     int bx_lo = 0, bx_hi = 0, bw_lo = 0, bw_hi = 0, nx = 0, bw_n = 0;   // buffer bases (this image / this wave's 16 weight rows) and the image's bytes
     auto rsrc_of = [&](int lo, int hi, int nbytes) {
@@ -648,7 +651,8 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     auto stage_first = [&]() {
         st_cb = 0, st_tap = 0, st_slot = 0;
 #pragma unroll
-        for (int t = 0; t < NPW; t++) stage_halo(t, 0, 0);
+        for (int t = 0; t < NPW; t++)
+            if (t < 6 || p6) stage_halo(t, 0, 0);
         for (int q = 0; q < AHEAD && q < np; q++) stage_w();
     };
     unsigned long long acc_t[6] = {0, 0, 0, 0, 0, 0}, t_prev = 0;   // DIAGNOSTIC (MASK bit 1024): cycles per section, summed over tiles
@@ -742,13 +746,13 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
                             stage_halo(3, cb + 1, (cb + 1) & 1);
                             stage_halo(4, cb + 1, (cb + 1) & 1);
                             stage_halo(5, cb + 1, (cb + 1) & 1);
-                            if (NPW == 7) stage_halo(6, cb + 1, (cb + 1) & 1);
+                            if (NPW == 7 && p6) stage_halo(6, cb + 1, (cb + 1) & 1);
                         }
                     } else if (tap <= 1) {
                         stage_halo(2 * tap, cb + 1, (cb + 1) & 1);
                         stage_halo(2 * tap + 1, cb + 1, (cb + 1) & 1);
                     } else if (tap <= NPW - 3) {
-                        stage_halo(tap + 2, cb + 1, (cb + 1) & 1);
+                        if (tap + 2 < 6 || p6) stage_halo(tap + 2, cb + 1, (cb + 1) & 1);
                     }
                 }
                 if (ph + AHEAD < np) stage_w();
@@ -806,8 +810,11 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
         tile_b(std::integral_constant<int, 6>{});
         tile_b(std::integral_constant<int, 7>{});
         __builtin_amdgcn_s_setprio(0);
-        if (ph + AHEAD < np) wait_vmcnt<in_flight>();
-        else wait_vmcnt<0>();     // the last phases issue nothing: nothing to wait for
+        // (a wave without a seventh piece has one load less in the window that holds it: taps 4..6 of nine, taps 0..1 of four)
+        constexpr bool has7 = halo && NPW == 7 && (NT == 9 ? (tap >= 4 && tap <= 6) : tap <= 1);
+        if (ph + AHEAD >= np) wait_vmcnt<0>();     // the last phases issue nothing: nothing to wait for
+        else if (has7 && !p6) wait_vmcnt<in_flight - (has7 ? 1 : 0)>();
+        else wait_vmcnt<in_flight>();
         __builtin_amdgcn_s_barrier();
         ++ph;
     };
