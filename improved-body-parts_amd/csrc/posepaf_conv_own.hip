@@ -531,8 +531,12 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
     // swizzle (bit 9) would make 14 of 16 start offsets 2-way conflicted.
     // Wave w loads pieces w, w + 8, ..., w + 48 of every channel block (see the DMA schedule).
     int hsrc[7];   // byte offset inside the image for channel block 0, or -1: zero page (outside the image / past the halo)
-    // The 128-wide tiles' halos take 49 pieces (52 dilated): a seventh piece for wave 0 (waves 0..3) only.  The other waves skip
-    // the instruction -- a load of nothing still costs its issue slot on the CU's one load path -- and count one less (below).
+    // A halo takes 39 .. 52 pieces: pieces 4, 5, 6 of a wave (32 + wave, 40 + wave, 48 + wave) exist for some waves only -- e.g.
+    // 49 pieces on the 128-wide tiles: a seventh for wave 0 alone; 42 on the 64-wide: a sixth for waves 0 and 1.  A wave skips the
+    // instructions of the pieces it does not own -- a load of nothing still costs its issue slot on the CU's one load path -- and
+    // counts that many loads less in the windows that hold them (`missing` below).
+    const bool p4 = __builtin_amdgcn_readfirstlane(32 + wave < hp.npieces);
+    const bool p5 = __builtin_amdgcn_readfirstlane(40 + wave < hp.npieces);
     const bool p6 = __builtin_amdgcn_readfirstlane(48 + wave < hp.npieces);
     unsigned woff = 0; // weight sub-tile of this wave: 16 output channels x 32 halves per phase (lane part of the offset)
     int bx_lo = 0, bx_hi = 0, bw_lo = 0, bw_hi = 0, nx = 0, bw_n = 0;   // buffer bases (this image / this wave's 16 weight rows) and the image's bytes
@@ -652,7 +656,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
         st_cb = 0, st_tap = 0, st_slot = 0;
 #pragma unroll
         for (int t = 0; t < NPW; t++)
-            if (t < 6 || p6) stage_halo(t, 0, 0);
+            if (t < 4 || (t == 4 && p4) || (t == 5 && p5) || (t == 6 && p6)) stage_halo(t, 0, 0);
         for (int q = 0; q < AHEAD && q < np; q++) stage_w();
     };
     unsigned long long acc_t[6] = {0, 0, 0, 0, 0, 0}, t_prev = 0;   // DIAGNOSTIC (MASK bit 1024): cycles per section, summed over tiles
@@ -744,15 +748,15 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
                             stage_halo(1, cb + 1, (cb + 1) & 1);
                             stage_halo(2, cb + 1, (cb + 1) & 1);
                             stage_halo(3, cb + 1, (cb + 1) & 1);
-                            stage_halo(4, cb + 1, (cb + 1) & 1);
-                            stage_halo(5, cb + 1, (cb + 1) & 1);
+                            if (p4) stage_halo(4, cb + 1, (cb + 1) & 1);
+                            if (p5) stage_halo(5, cb + 1, (cb + 1) & 1);
                             if (NPW == 7 && p6) stage_halo(6, cb + 1, (cb + 1) & 1);
                         }
                     } else if (tap <= 1) {
                         stage_halo(2 * tap, cb + 1, (cb + 1) & 1);
                         stage_halo(2 * tap + 1, cb + 1, (cb + 1) & 1);
                     } else if (tap <= NPW - 3) {
-                        if (tap + 2 < 6 || p6) stage_halo(tap + 2, cb + 1, (cb + 1) & 1);
+                        if (tap == 2 ? p4 : (tap == 3 ? p5 : p6)) stage_halo(tap + 2, cb + 1, (cb + 1) & 1);
                     }
                 }
                 if (ph + AHEAD < np) stage_w();
@@ -810,11 +814,18 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_halo(const ConvParams p, c
         tile_b(std::integral_constant<int, 6>{});
         tile_b(std::integral_constant<int, 7>{});
         __builtin_amdgcn_s_setprio(0);
-        // (a wave without a seventh piece has one load less in the window that holds it: taps 4..6 of nine, taps 0..1 of four)
-        constexpr bool has7 = halo && NPW == 7 && (NT == 9 ? (tap >= 4 && tap <= 6) : tap <= 1);
+        // pieces this wave did NOT issue inside the window of this tap's wait (piece 4 / 5 / 6 goes out at tap 2 / 3 / 4 of nine and
+        // stays in the window for three taps; all go out at tap 0 of four and stay for taps 0 and 1): wave-uniform, 0 .. 3
+        constexpr bool w4 = halo && (NT == 9 ? (tap >= 2 && tap <= 4) : tap <= 1);
+        constexpr bool w5 = halo && (NT == 9 ? (tap >= 3 && tap <= 5) : tap <= 1);
+        constexpr bool w6 = halo && NPW == 7 && (NT == 9 ? (tap >= 4 && tap <= 6) : tap <= 1);
+        const int missing = (w4 && !p4) + (w5 && !p5) + (w6 && !p6);
+        static_assert(in_flight >= 3, "the window always holds the three weight slices");
         if (ph + AHEAD >= np) wait_vmcnt<0>();     // the last phases issue nothing: nothing to wait for
-        else if (has7 && !p6) wait_vmcnt<in_flight - (has7 ? 1 : 0)>();
-        else wait_vmcnt<in_flight>();
+        else if (missing == 0) wait_vmcnt<in_flight>();
+        else if (missing == 1) wait_vmcnt<(in_flight > 1 ? in_flight - 1 : 0)>();
+        else if (missing == 2) wait_vmcnt<(in_flight > 2 ? in_flight - 2 : 0)>();
+        else wait_vmcnt<(in_flight > 3 ? in_flight - 3 : 0)>();
         __builtin_amdgcn_s_barrier();
         ++ph;
     };
@@ -943,7 +954,8 @@ bool halo_geometry(const ConvParams &p, HaloParams &g) {
         g.nhalo = g.gimg * (p.H + 2) * (tw + 2);
     }
     g.npieces = (g.nhalo + 15) / 16;
-    return g.npieces <= (g.lgTW == 7 || p.dil > 1 ? 56 : 48);   // 7 pieces per wave and channel block (six for the narrower tiles: NPW)
+    // 7 pieces per wave and channel block (six for the narrower tiles: NPW); the first four of every wave always exist
+    return g.npieces >= 32 && g.npieces <= (g.lgTW == 7 || p.dil > 1 ? 56 : 48);
 }
 
 
