@@ -1205,7 +1205,13 @@ int launch_pw_form(const PwParams &p, int n_split, hipStream_t st) {
             return PP_ERR_HIP;
         ds->ncu = n >= 8 ? (n / 8) * 8 : 8;
     }
-    const int per_cu = lds <= 40 * 1024 ? 3 : (lds <= 76 * 1024 ? 2 : 1);   // workgroups that fit a CU's 160 KiB of LDS
+    // persistent grid: as many workgroups as are RESIDENT at once (registers and LDS decide: most forms hold one 8-wave workgroup
+    // per CU, the leanest two) -- a workgroup beyond that would start when another ends and load the weights once more
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&k_pw<KT, PT, EX, POOL>), 512, (size_t)lds) !=
+            hipSuccess || per_cu < 1)
+        per_cu = 1;
+    if (per_cu > 3) per_cu = 3;
     const long groups = (p.M + PT * 16 - 1) / (PT * 16);
     long gx = (long)ds->ncu * per_cu / n_split;
     if (gx < 1) gx = 1;
