@@ -1348,7 +1348,7 @@ extern "C" {
 // y = act(conv1x1(x * scale[n]) + bias (+ extra)) [, y2 = y + extra2]: see k_pw.  x: DEVICE (m, c_in) fp16 (an NHWC activation,
 // m = n * h * w pixels); scale: DEVICE (m / hw, c_in) fp16 or NULL; w: DEVICE (c_out, c_in); bias fp16[c_out]; extra / extra2 /
 // y2: DEVICE (m, c_out) or NULL; y: DEVICE, pixel stride ldy >= c_out.  extra_mode as pp_conv_own_ex_f16 (0, 1, 2, 4).
-// c_in in {64, 128, 192, 256, 384, 512}, c_out % 64 == 0, hw % 32 == 0 when scale is given; PP_ERR_UNSUPPORTED otherwise.
+// c_in in {64, 128, 192, 256, 384, 448, 512, 640, 704}, c_out % 64 == 0, hw % 64 == 0 when scale is given; PP_ERR_UNSUPPORTED otherwise.
 PP_API int pp_pw_supported(int c_in, int c_out) {
     return ((c_in == 64 || c_in == 128 || c_in == 192 || c_in == 256 || c_in == 384 || c_in == 448 || c_in == 512 || c_in == 640 || c_in == 704) && c_out % 64 == 0 && c_out >= 64) ? 1 : 0;
 }

@@ -261,7 +261,7 @@ PP_API int pp_conv_up2_collapsed_f16(const void *x, const void *w4, const void *
  * separate x * s pass would; w: DEVICE (c_out, c_in); bias fp16[c_out]; extra / extra2 / y2: DEVICE (m, c_out) or NULL;
  * y: DEVICE with ldy >= c_out elements between pixels (a channel slice of a wider tensor when larger); hw = h * w.
  * extra_mode 0 / 1 / 2 / 4 as pp_conv_own_ex_f16; 5 = the second output y2 = y + extra2 without a tensor added before the
- * activation (extra = NULL).  pp_pw_supported: c_in in {64, 128, 192, 256, 384, 512}, c_out % 64 == 0;
+ * activation (extra = NULL).  pp_pw_supported: c_in in {64, 128, 192, 256, 384, 448, 512, 640, 704} (the sums of a two-input call included), c_out % 64 == 0;
  * with `scale`, hw % 64 == 0 (a group of pixels must not straddle two images). */
 PP_API int pp_pw_supported(int c_in, int c_out);
 PP_API int pp_pw_f16(const void *x, const void *scale, const void *w, const void *bias, const void *extra, const void *extra2, void *y,
