@@ -250,7 +250,7 @@ class StubEngine:
         pass
 
     def verify(self, rec):
-        return {"ok": True, "stub": True}
+        return {"ok": os.environ.get("POSEPAF_BENCH_STUB_VERIFY", "ok") != "fail", "stub": True}
 
     def oracle_sample(self, rec, n=8):
         return None

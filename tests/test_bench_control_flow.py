@@ -65,6 +65,16 @@ def test_bad_status_words_fail_the_run(status, code):
         assert "INVALID" in r.stderr
 
 
+def test_a_failed_recomputation_fails_the_run():
+    """verify() -- records vs the separate-assembly launch, forward vs the plain module, forward twice bit-identical -- saying no
+    on ANY rank invalidates the line: exit code 3, the verdict in the JSON"""
+    r, lines = _run(["--steps", "1", "--warmup", "0", "--batch", "2"], POSEPAF_BENCH_STUB_VERIFY="fail")
+    assert r.returncode == 3 and "INVALID" in r.stderr
+    assert len(lines) == 1 and json.loads(lines[0])["verify"]["ok"] is False
+    r, lines = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "2"], POSEPAF_BENCH_STUB_VERIFY="fail")
+    assert r.returncode != 0 and len(lines) == 1 and json.loads(lines[0])["verify"]["ok"] is False
+
+
 def test_gpus_mismatch_is_refused():
     env = dict(os.environ, POSEPAF_BENCH_STUB="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1"], env=env,
