@@ -2,7 +2,7 @@
 """Per-kernel means of rocprofv3 --pmc counters (one pass = one directory), summed over the XCDs / instances of a dispatch and
 averaged over the dispatches of each kernel whose name contains one of the given patterns.
 
-    python tools/pmc_summary.py <out.json> <pattern[,pattern...]> <pass dir> [<pass dir> ...]
+    python tools/pmc_summary.py <out.json> <pattern[,pattern...] or pattern;pattern...> <pass dir> [<pass dir> ...]
 """
 import collections
 import csv
@@ -11,7 +11,8 @@ import json
 import os
 import sys
 
-out_path, pats, dirs = sys.argv[1], sys.argv[2].split(","), sys.argv[3:]
+out_path, dirs = sys.argv[1], sys.argv[3:]
+pats = sys.argv[2].split(";") if ";" in sys.argv[2] else sys.argv[2].split(",")   # (template names hold commas: use ";" for them)
 res = {p: {} for p in pats}
 for d in dirs:
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
